@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the Env01 PPO rollout at 4096 envs/GPU (BASELINE.json metric).
+
+One "step" = one vectorised env step of the rollout loop on every rank: policy forward (SB3 MlpPolicy shape:
+separate 2x64 tanh towers for pi and V, state-independent log-std Gaussian), action sampling + clipping, the fused
+HIP env step (reward -> ctrl -> 16 physics substeps -> obs -> TimeLimit -> auto-reset), and the write of
+obs/action/reward/done/value/log-prob into the on-device rollout buffer; every ROLLOUT_T steps the rollout chunk is
+gathered to the learner rank over RCCL (N > 1 only).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
+GPU, contact disabled / no constraint solver (cube pinned), synthetic randomized-reset batches, random-init policy.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (so100_step_fused) with the algorithmic
+452 B/env-step of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a port, not the reference) on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_ENV_STEP = 452.0        # SURVEY.md section 8(d), Env01, fp32 SoA, 16 substeps fused
+FLOP_PER_ENV_STEP = 6.0e4         # SURVEY.md section 8(d), constraint-free
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
+VALU_PEAK_TFLOPS = 157.3
+ROLLOUT_T = 64
+
+
+class MlpPolicy:
+    """SB3 ActorCriticPolicy("MlpPolicy") forward for a Box action space, random init, on the device."""
+
+    def __init__(self, obs_dim, act_dim, device, seed):
+        g = torch.Generator(device="cpu"); g.manual_seed(seed)
+        def lin(i, o, gain):
+            w = torch.empty(o, i); torch.nn.init.orthogonal_(w, gain=gain, generator=g)
+            return w.t().contiguous().to(device), torch.zeros(o, device=device)
+        s2 = 2 ** 0.5
+        self.pi = [lin(obs_dim, 64, s2), lin(64, 64, s2)]; self.vf = [lin(obs_dim, 64, s2), lin(64, 64, s2)]
+        self.mu = lin(64, act_dim, 0.01); self.v = lin(64, 1, 1.0)
+        self.log_std = torch.zeros(act_dim, device=device)
+        self.act_dim = act_dim
+
+    @torch.no_grad()
+    def forward(self, obs, noise):
+        h = obs
+        for w, b in self.pi:
+            h = torch.tanh(torch.addmm(b, h, w))
+        mean = torch.addmm(self.mu[1], h, self.mu[0])
+        g = obs
+        for w, b in self.vf:
+            g = torch.tanh(torch.addmm(b, g, w))
+        value = torch.addmm(self.v[1], g, self.v[0]).squeeze(1)
+        std = self.log_std.exp()
+        act = mean + std * noise
+        logp = (-0.5 * noise.pow(2) - self.log_std - 0.9189385332046727).sum(1)
+        return act, value, logp
+
+
+def cpu_baseline(kind, flags, iters, seconds=12.0):
+    """The oracle (a CPU port of the same step) on the host cores: one env slice per thread."""
+    import numpy as np
+    from oracle import so100_oracle as O
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    n = 64 * threads
+    b = O.OracleBatch(kind, n, flags, iters, seed=1234)
+    b.reset()
+    rs = np.random.RandomState(0)
+    acts = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
+    b.step(acts, threads=threads)                          # warm-up
+    t0 = time.perf_counter(); steps = 0
+    while time.perf_counter() - t0 < seconds:
+        b.step(acts, threads=threads); steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{n} Env01 envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads, same flags/solver iterations"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_reference", "env02_reference", "env05_reference"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE
+    kind, flags = {"env01_free": (1, F_CUBE_PINNED), "env01_reference": (1, F_REFERENCE),
+                   "env02_reference": (2, F_REFERENCE), "env05_reference": (5, F_REFERENCE)}[args.workload]
+    n = args.envs
+    sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=3, contact_iters=4, seed=1234 + rank, env_id_offset=rank * n)
+    obs = sim.reset()
+    # stagger the episodes so TimeLimit resets are spread over the rollout
+    g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
+    sim.set_field("elapsed_steps", torch.randint(0, sim.cfg.max_episode_steps, (n,), device=dev, generator=g, dtype=torch.int32))
+    pol = MlpPolicy(sim.obs_dim, 6, dev, seed=0)
+    T = ROLLOUT_T
+    k = sim.obs_dim + 6 + 4                                  # obs, action, reward, done, value, logp
+    chunk = torch.zeros(T, n, k, device=dev)
+    gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    noise = torch.empty(n, 6, device=dev)
+
+    def vec_step(t):
+        noise.normal_(generator=g)
+        act, value, logp = pol.forward(obs, noise)
+        row = chunk[t % T]
+        row[:, :sim.obs_dim] = obs
+        act = act.clamp_(-1.0, 1.0)
+        ob, rew, done, trunc = sim.step(act)
+        row[:, sim.obs_dim:sim.obs_dim + 6] = act
+        row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
+        if world > 1 and (t + 1) % T == 0:
+            dist.gather(chunk, gathered, dst=0)              # RCCL: rollout chunk -> learner rank
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for t in range(args.warmup):
+        vec_step(t)
+    sync()
+    t0 = time.perf_counter()
+    for t in range(args.steps):
+        vec_step(t)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+
+    # dominant kernel alone: HIP events on the launch stream around back-to-back so100_step launches
+    act = torch.rand(n, 6, device=dev) * 2 - 1
+    for _ in range(20):
+        sim.step(act)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    reps = 200
+    torch.cuda.synchronize(dev)
+    e0.record()
+    for _ in range(reps):
+        sim.step(act)
+    e1.record(); torch.cuda.synchronize(dev)
+    kern_ms = e0.elapsed_time(e1) / reps
+
+    if rank == 0:
+        value = world * n * args.steps / dt
+        achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "env steps/sec at 4096 envs/GPU, Env01 PPO rollout", "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: Env{kind:02d} x {n} envs/GPU, frame_skip 16, "
+                                   + ("contact disabled, no constraint solver (BASELINE.json configs[1])" if args.workload == "env01_free" else "friction-loss + limits + cube/floor contact")
+                                   + ", SB3-MlpPolicy-shaped rollout, randomized resets, staggered episodes",
+                       "envs_per_gpu": n, "rollout_chunk": T, "parallelism": f"env-sharded x{world}, RCCL gather per chunk" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "so100_step_fused", "kernel_ms": kern_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP,
+                         "kernel_env_steps_per_s": n / (kern_ms * 1e-3),
+                         "valu": {"achieved_tflops": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                                  "frac": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, flags, 3)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

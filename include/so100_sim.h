@@ -1,0 +1,111 @@
+/* so100_sim.h -- C ABI of libso100sim.so: the MI355X-native batched so100 simulator.
+ *
+ * This is the drop-in boundary for the ONE hot path of PieterBecking/so100-mujoco-rl: the per-env
+ * step behind its Gymnasium / Stable-Baselines3 surface.  Nothing comparable exists in the reference
+ * (its Python <-> C crossing is pybind11 `mujoco.mj_step(MjModel, MjData, nstep)`: opaque structs,
+ * fp64, one env); each entry point below names the reference interface it replaces.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  All `*_dev` pointers are DEVICE pointers
+ *     owned by the caller (e.g. tensor.data_ptr()); persistent sim state is owned by the handle.
+ *   - every call returns 0 on success, a negative SO100_E_* code otherwise; the message is available
+ *     from so100_last_error() (thread local).  Nothing throws across the ABI.
+ *   - all work is enqueued on the caller's `hip_stream` (a hipStream_t; NULL = default stream);
+ *     so100_step / so100_reset allocate nothing, free nothing and never synchronise
+ *     (hipGraph-capturable).
+ *   - one handle per process per device; a handle is not thread safe.
+ *   - there is NO CPU fallback: without a usable HIP device so100_create fails.
+ *
+ * Reference files cited as "ref:" live under /root/reference/src/so100_mujoco_rl/.
+ */
+#ifndef SO100_SIM_H
+#define SO100_SIM_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SO100_ABI_VERSION 1
+
+/* env kinds == the reference's registered ids Env01-v1 .. Env05-v1 (ref: __init__.py:5-38) */
+#define SO100_ENV01 1   /* ref: envs/env01_v1.py  reach, random start pose              obs 15 */
+#define SO100_ENV02 2   /* ref: envs/env02_v1.py  reach + re-randomise on reach         obs 15 */
+#define SO100_ENV03 3   /* ref: envs/env03_v1.py  look-at, moving cube (analytic detector) obs 8 */
+#define SO100_ENV04 4   /* ref: envs/env04_v1.py  look-at, jumping cube (analytic detector) obs 8 */
+#define SO100_ENV05 5   /* ref: envs/env05_v1.py  look-at, analytic reprojection + noise  obs 8 */
+
+/* physics option flags (which MuJoCo constraint families are simulated) */
+#define SO100_F_FRICTIONLOSS 1u   /* joint friction loss 0.1 (model/so_arm100_camera.xml:32)        */
+#define SO100_F_LIMITS       2u   /* joint range limits (model/so_arm100_camera.xml:35-50)           */
+#define SO100_F_FLOOR        4u   /* cube / floor box-plane contact (model/env01.xml:32,39)          */
+#define SO100_F_CUBE_PINNED  8u   /* cube kinematic (BASELINE.json configs[1]: "contact disabled")   */
+#define SO100_F_REFERENCE (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR)
+
+#define SO100_E_INVALID  (-1)     /* bad argument                                   */
+#define SO100_E_NODEVICE (-2)     /* no usable HIP device / HIP runtime failure      */
+#define SO100_E_NOMEM    (-3)
+#define SO100_E_LAUNCH   (-4)
+
+#define SO100_NINJECT 16          /* per env: [0..7] step-phase uniforms, [8..15] reset-phase */
+
+typedef struct so100_sim so100_sim;
+
+typedef struct {
+    int32_t  env_kind;            /* SO100_ENV01..05                                               */
+    int32_t  num_envs;            /* N, any positive number                                        */
+    int32_t  device;              /* HIP device ordinal                                            */
+    uint32_t flags;               /* SO100_F_*                                                     */
+    int32_t  solver_iters;        /* block-PGS sweeps over the arm rows (>= 1; 3 reaches fp32)     */
+    int32_t  contact_iters;       /* Newton iterations of the cube/floor block (>= 1; 4 typical)   */
+    int32_t  frame_skip;          /* physics substeps per env step; 16 (ref: envs/env_base_01.py:45) */
+    int32_t  max_episode_steps;   /* TimeLimit: 4000 Env01, 6000 others (ref: __init__.py:8,15); 0 = none */
+    uint64_t seed;                /* Philox key                                                    */
+    uint32_t env_id_offset;       /* global id of env 0 (rank * N): makes sharded runs reproducible */
+    uint32_t reserved;
+} so100_config;
+
+/* One vectorised env step.  Replaces, for N envs at once, the reference chain
+ *   SB3 DummyVecEnv.step_wait -> gymnasium TimeLimit.step -> EnvNN.step (ref: envs/env01_v1.py:15-37 and
+ *   clones) -> mujoco.mj_step(model, data, nstep=16) -> _get_obs, including DummyVecEnv's auto-reset. */
+typedef struct {
+    const float* act_dev;          /* [N][6]  f32 in [-1,1] (ref: envs/env_base_01.py:77-83)          */
+    float*       obs_dev;          /* [N][obs_dim] f32; post-auto-reset observation where done        */
+    float*       rew_dev;          /* [N] f32                                                         */
+    uint8_t*     done_dev;         /* [N] terminated || truncated                                     */
+    uint8_t*     trunc_dev;        /* [N] info["TimeLimit.truncated"] = truncated && !terminated      */
+    float*       terminal_obs_dev; /* [N][obs_dim] info["terminal_observation"], written where done; nullable */
+    float*       ep_return_dev;    /* [N] Monitor's info["episode"]["r"], written where done; nullable */
+    int32_t*     ep_length_dev;    /* [N] Monitor's info["episode"]["l"], written where done; nullable */
+    const float* inject_dev;       /* [N][SO100_NINJECT] uniforms replacing the device RNG (parity tests); nullable */
+} so100_step_io;
+
+int  so100_abi_version(void);
+int  so100_obs_dim(int32_t env_kind);                     /* ref: env_base_01.py:63-75 (15), env_base_02.py:56-69 (8) */
+int  so100_num_state_fields(void);                        /* rows of the [field][N] state matrix */
+int  so100_state_field_index(const char* name);           /* e.g. "q0", "elapsed_steps"; -1 if unknown */
+
+/* ref: gym.make(id) -> EnvNN.__init__ -> mujoco.MjModel.from_xml_path + MujocoEnv.__init__
+ * (envs/env_base_01.py:35-51).  The model is compiled in (csrc/so100_model_def.h). */
+int  so100_create(const so100_config* cfg, so100_sim** out);
+void so100_destroy(so100_sim* sim);
+
+/* ref: MujocoEnv.reset -> mj_resetData -> EnvNN.reset_model (envs/env01_v1.py:39-63 and clones).
+ * mask_dev: [N] bytes, non-zero = reset that env; NULL = all.  obs_dev rows of untouched envs are left alone. */
+int  so100_reset(so100_sim* sim, const uint8_t* mask_dev, const float* inject_dev, float* obs_dev, void* hip_stream);
+
+int  so100_step(so100_sim* sim, const so100_step_io* io, void* hip_stream);
+
+/* ref: reads / writes of data.qpos, data.qvel (MjData), SoA: qpos_dev [13][N], qvel_dev [12][N] */
+int  so100_get_state(so100_sim* sim, float* qpos_dev, float* qvel_dev, void* hip_stream);
+int  so100_set_state(so100_sim* sim, const float* qpos_dev, const float* qvel_dev, void* hip_stream);
+/* any single row of the state matrix ([N] 4-byte words; integer rows are int32 bit patterns) */
+int  so100_get_field(so100_sim* sim, int32_t field, void* out_dev, void* hip_stream);
+int  so100_set_field(so100_sim* sim, int32_t field, const void* in_dev, void* hip_stream);
+
+const char* so100_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SO100_SIM_H */

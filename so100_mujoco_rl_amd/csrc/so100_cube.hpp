@@ -1,0 +1,249 @@
+// so100_cube.hpp -- the free-joint cube "block_a" and its box/plane contact with the floor.
+//
+// Reference: scene:29-35 (body, free joint, box geom half size 0.01), scene:39 (floor plane z = 0).
+// MuJoCo stages restated (Appendix A.4):
+//   mjc_PlaneBox narrowphase (<= 4 corner contacts), pyramidal friction cone (condim 3, mu = 1):
+//   4 edge rows per contact with J = n +- mu t_k, aref = -B Jv - K imp dist, R = 2 mu^2 (1-imp)/imp * 2/m,
+//   force >= 0 per edge, semi-implicit Euler with mju_quatIntegrate for the orientation.
+// Solver: the 16 edge rows of a resting cube are highly redundant (rank <= 6), so scalar PGS on the dual
+// needs > 100 sweeps for 1e-5 (measured against the oracle).  This block is therefore solved in the
+// PRIMAL, like MuJoCo's default Newton solver: minimise over x = qacc - qacc_smooth (6 numbers)
+//     1/2 x'Mx + sum_r 1/(2 R_r) min(0, b_r + J_r x)^2 ,      M = diag(m,m,m,I,I,I),
+// by Newton with an exact bracketed line search along each direction (the cost along a ray is a convex
+// piecewise quadratic): a 6x6 LDL^T per iteration, 2-4 iterations.
+// It reaches the same optimum as the oracle's PGS-to-convergence (tests/test_hostcheck.py).
+// The cube is dynamically decoupled from the arm (no arm-cube contact is modelled: the reference
+// excludes block_a against 5 of the 7 arm bodies, scene:44-48, and the remaining mesh geoms are not
+// available), so its 6x6 mass matrix is the constant diag(m,m,m,I,I,I) and its rows are solved on their own.
+//
+// Everything is indexed statically (4 contact slots x 4 edges) so that it stays in registers.
+#pragma once
+#include "so100_physics.hpp"
+
+namespace so100 {
+
+template <typename T> struct Cube {
+    T pos[3], quat[4], vel[6];     // vel = (linear, world frame; angular, body frame) like MuJoCo qvel
+    T warm[6];                     // previous x = qacc - qacc_smooth (Newton warm start)
+};
+
+template <typename T> SO100_HD void quat_to_mat(const T q[4], T m[9]) {
+    const T w = q[0], x = q[1], y = q[2], z = q[3];
+    m[0] = w*w + x*x - y*y - z*z; m[1] = T(2)*(x*y - w*z);       m[2] = T(2)*(x*z + w*y);
+    m[3] = T(2)*(x*y + w*z);       m[4] = w*w - x*x + y*y - z*z; m[5] = T(2)*(y*z - w*x);
+    m[6] = T(2)*(x*z - w*y);       m[7] = T(2)*(y*z + w*x);       m[8] = w*w - x*x - y*y + z*z;
+}
+template <typename T> SO100_HD void quat_normalize(T q[4]) {
+    const T n = tsqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
+    if (n < T(1e-15)) { q[0] = T(1); q[1] = q[2] = q[3] = T(0); return; }
+    const T r = T(1)/n;
+    q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
+}
+
+// the four pyramid edge directions n +- mu t1, n +- mu t2 with n = +z, t1 = +y, t2 = -x, mu = 1
+// (mju_makeFrame for a +z normal), in the oracle's row order
+template <int E> struct EdgeDir;
+template <> struct EdgeDir<0> { static constexpr double d[3] = { 0,  1, 1 }; };
+template <> struct EdgeDir<1> { static constexpr double d[3] = { 0, -1, 1 }; };
+template <> struct EdgeDir<2> { static constexpr double d[3] = { -1, 0, 1 }; };
+template <> struct EdgeDir<3> { static constexpr double d[3] = { 1,  0, 1 }; };
+
+template <typename T> struct CubeRows {
+    bool act[4];
+    T rl[4][3];        // contact point relative to the cube centre, body frame
+    T dl[4][3];        // edge directions in the body frame (shared by the 4 contacts)
+    T b[4][4], R[4], arinv[4][4];
+};
+
+// row (S,E): jar = b + J x,  J = [dir_E ; rl[S] x dl[E]];  accumulates cost / gradient / Hessian
+template <int S, int E, typename T>
+SO100_HD void cube_row_accum(const CubeRows<T>& r, const T x[6], T& cost, T g[6], T Hm[21], bool want_gh) {
+    T J[6];
+    J[0] = T(EdgeDir<E>::d[0]); J[1] = T(EdgeDir<E>::d[1]); J[2] = T(EdgeDir<E>::d[2]);
+    cross(r.rl[S], r.dl[E], J + 3);
+    T jar = r.b[S][E];
+#pragma unroll
+    for (int i = 0; i < 6; i++) jar += J[i]*x[i];
+    const bool on = r.act[S] && jar < T(0);
+    const T D = on ? r.arinv[S][E] : T(0);             // 1/R of the row when active
+    cost += T(0.5)*D*jar*jar;
+    if (want_gh) {
+        const T dj = D*jar;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            g[i] += dj*J[i];
+            const T dji = D*J[i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) Hm[SO100_TRI(i, j)] += dji*J[j];
+        }
+    }
+}
+template <typename T>
+SO100_HD T cube_rows_eval(const CubeRows<T>& r, const T x[6], T g[6], T Hm[21], bool want_gh) {
+    const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+    T cost = T(0.5)*(m*(x[0]*x[0] + x[1]*x[1] + x[2]*x[2]) + I*(x[3]*x[3] + x[4]*x[4] + x[5]*x[5]));
+    if (want_gh) {
+#pragma unroll
+        for (int i = 0; i < 21; i++) Hm[i] = T(0);
+#pragma unroll
+        for (int i = 0; i < 3; i++) { g[i] = m*x[i]; g[3+i] = I*x[3+i]; Hm[SO100_TRI(i, i)] = m; Hm[SO100_TRI(3+i, 3+i)] = I; }
+    }
+#define SO100_ACC(S) cube_row_accum<S, 0>(r, x, cost, g, Hm, want_gh); cube_row_accum<S, 1>(r, x, cost, g, Hm, want_gh); \
+                     cube_row_accum<S, 2>(r, x, cost, g, Hm, want_gh); cube_row_accum<S, 3>(r, x, cost, g, Hm, want_gh);
+    SO100_ACC(0) SO100_ACC(1) SO100_ACC(2) SO100_ACC(3)
+#undef SO100_ACC
+    return cost;
+}
+// line-search helpers: per row jar(alpha) = j0 + alpha jd
+template <int S, int E, typename T>
+SO100_HD void cube_row_lin(const CubeRows<T>& r, const T x[6], const T dx[6], T j0[4][4], T jd[4][4]) {
+    T J[6];
+    J[0] = T(EdgeDir<E>::d[0]); J[1] = T(EdgeDir<E>::d[1]); J[2] = T(EdgeDir<E>::d[2]);
+    cross(r.rl[S], r.dl[E], J + 3);
+    T a = r.b[S][E], b = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a += J[i]*x[i]; b += J[i]*dx[i]; }
+    j0[S][E] = a; jd[S][E] = b;
+}
+template <typename T>
+SO100_HD void cube_phi(const CubeRows<T>& r, const T j0[4][4], const T jd[4][4], T q1, T q2, T alpha, T& d1, T& d2) {
+    d1 = q1 + alpha*q2; d2 = q2;                       // quadratic part: (x + alpha dx)'M dx, dx'M dx
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const T t = j0[s][e] + alpha*jd[s][e];
+            const T D = (r.act[s] && t < T(0)) ? r.arinv[s][e] : T(0);
+            d1 += D*t*jd[s][e]; d2 += D*jd[s][e]*jd[s][e];
+        }
+}
+template <int S, int E, typename T>
+SO100_HD void cube_row_setup(CubeRows<T>& r, const T a0[3], const T vl[3], const T va[3], T Kimpdist) {
+    T ja[3]; cross(r.rl[S], r.dl[E], ja);
+    const T d0 = T(EdgeDir<E>::d[0]), d1 = T(EdgeDir<E>::d[1]), d2 = T(EdgeDir<E>::d[2]);
+    const T jv = d0*vl[0] + d1*vl[1] + d2*vl[2] + dot(ja, va);
+    const T ja0 = d0*a0[0] + d1*a0[1] + d2*a0[2];                 // angular a0 is zero (isotropic, no torque)
+    r.b[S][E] = ja0 + T(so100g::SOLREF_B)*jv + Kimpdist;
+    r.arinv[S][E] = T(1)/r.R[S];
+}
+
+template <typename T>
+SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int iters) {
+    if (flags & F_CUBE_PINNED) return;
+    const T h = T(so100g::TIMESTEP);
+    const T im = T(1.0/so100g::CUBE_MASS);
+    // qacc_smooth: gravity + applied force (Env03-05 anti-gravity); no gyroscopic term (isotropic inertia)
+    const T a0[3] = { applied[0]*im, applied[1]*im, applied[2]*im - T(so100g::GRAVITY) };
+    T al[3] = { a0[0], a0[1], a0[2] }, aa[3] = { T(0), T(0), T(0) };
+
+    if (flags & F_FLOOR) {
+        T qn[4] = { c.quat[0], c.quat[1], c.quat[2], c.quat[3] };
+        quat_normalize(qn);
+        T Rm[9]; quat_to_mat(qn, Rm);
+        CubeRows<T> r;
+        // ---- mjc_PlaneBox: corners below the centre and at / below the plane; first four in corner order
+        const T hs = T(so100g::CUBE_HALF);
+        const T cdist = c.pos[2];
+        bool hit[8]; T dist8[8]; int slot[8]; int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const T sx = (k & 1) ? hs : -hs, sy = (k & 2) ? hs : -hs, sz = (k & 4) ? hs : -hs;
+            const T ld = Rm[6]*sx + Rm[7]*sy + Rm[8]*sz;
+            const bool hk = !(cdist + ld > T(0) || ld > T(0)) && cnt < 4;
+            hit[k] = hk; dist8[k] = cdist + ld; slot[k] = cnt; cnt += hk ? 1 : 0;
+        }
+        T dist[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            r.act[s] = false; dist[s] = T(0);
+            T v[3] = { T(0), T(0), T(0) };
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool sel = hit[k] && slot[k] == s;
+                if (sel) {
+                    r.act[s] = true; dist[s] = dist8[k];
+                    v[0] = (k & 1) ? hs : -hs; v[1] = (k & 2) ? hs : -hs; v[2] = (k & 4) ? hs : -hs;
+                }
+            }
+            // contact point = corner - n dist/2; relative to the centre, in the body frame: v - R^T n dist/2
+            const T hd = T(0.5)*dist[s];
+            r.rl[s][0] = v[0] - Rm[6]*hd; r.rl[s][1] = v[1] - Rm[7]*hd; r.rl[s][2] = v[2] - Rm[8]*hd;
+            const T imp = impedance(tabs(dist[s]));
+            // R = 2 mu^2 * (1-imp)/imp * diagApprox, diagApprox = (1 + mu^2)/m, mu = 1
+            r.R[s] = T(4.0/so100g::CUBE_MASS)*(T(1) - imp)/imp;
+            dist[s] = T(so100g::SOLREF_K)*imp*dist[s];            // K imp dist
+        }
+        // edge directions in the body frame: dl = R^T dir
+#define SO100_DL(E) { const T d0 = T(EdgeDir<E>::d[0]), d1 = T(EdgeDir<E>::d[1]), d2 = T(EdgeDir<E>::d[2]); \
+            r.dl[E][0] = Rm[0]*d0 + Rm[3]*d1 + Rm[6]*d2; r.dl[E][1] = Rm[1]*d0 + Rm[4]*d1 + Rm[7]*d2; r.dl[E][2] = Rm[2]*d0 + Rm[5]*d1 + Rm[8]*d2; }
+        SO100_DL(0) SO100_DL(1) SO100_DL(2) SO100_DL(3)
+#undef SO100_DL
+        const T vl[3] = { c.vel[0], c.vel[1], c.vel[2] }, va[3] = { c.vel[3], c.vel[4], c.vel[5] };
+#define SO100_SETUP(S) cube_row_setup<S, 0>(r, a0, vl, va, dist[S]); cube_row_setup<S, 1>(r, a0, vl, va, dist[S]); \
+                       cube_row_setup<S, 2>(r, a0, vl, va, dist[S]); cube_row_setup<S, 3>(r, a0, vl, va, dist[S]);
+        SO100_SETUP(0) SO100_SETUP(1) SO100_SETUP(2) SO100_SETUP(3)
+#undef SO100_SETUP
+        // Newton on x = qacc - qacc_smooth, warm-started from the previous substep
+        T x[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = r.act[0] ? c.warm[i] : T(0);
+        if (r.act[0]) {                                   // slot 0 is filled first: no contact => x = 0
+            const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+            for (int it = 0; it < iters; it++) {
+                T g[6], Hm[21], Dinv[6], dx[6];
+                cube_rows_eval(r, x, g, Hm, true);
+#pragma unroll
+                for (int i = 0; i < 6; i++) dx[i] = -g[i];
+                ldl6(Hm, Dinv);
+                ldl6_solve(Hm, Dinv, dx);
+                // exact line search: phi'(alpha) is increasing and piecewise linear; root by safeguarded Newton
+                T j0[4][4], jd[4][4];
+#define SO100_LIN(S) cube_row_lin<S, 0>(r, x, dx, j0, jd); cube_row_lin<S, 1>(r, x, dx, j0, jd); \
+                     cube_row_lin<S, 2>(r, x, dx, j0, jd); cube_row_lin<S, 3>(r, x, dx, j0, jd);
+                SO100_LIN(0) SO100_LIN(1) SO100_LIN(2) SO100_LIN(3)
+#undef SO100_LIN
+                const T q1 = m*(x[0]*dx[0] + x[1]*dx[1] + x[2]*dx[2]) + I*(x[3]*dx[3] + x[4]*dx[4] + x[5]*dx[5]);
+                const T q2 = m*(dx[0]*dx[0] + dx[1]*dx[1] + dx[2]*dx[2]) + I*(dx[3]*dx[3] + dx[4]*dx[4] + dx[5]*dx[5]);
+                T lo = T(0), hi = T(-1), alpha = T(1), d1, d2;      // hi < 0: no upper bracket yet
+#pragma unroll 1
+                for (int ls = 0; ls < 10; ls++) {
+                    cube_phi(r, j0, jd, q1, q2, alpha, d1, d2);
+                    if (d1 < T(0)) lo = alpha; else hi = alpha;
+                    T an = d2 > T(0) ? alpha - d1/d2 : alpha;
+                    const bool inside = an > lo && (hi < T(0) || an < hi);
+                    if (!inside) an = hi < T(0) ? T(2)*alpha : T(0.5)*(lo + hi);
+                    if (an == alpha) break;
+                    alpha = an;
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) x[i] += alpha*dx[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) c.warm[i] = x[i];
+        const T wl[3] = { x[0], x[1], x[2] }, wa[3] = { x[3], x[4], x[5] };
+        al[0] += wl[0]; al[1] += wl[1]; al[2] += wl[2];
+        aa[0] = wa[0]; aa[1] = wa[1]; aa[2] = wa[2];
+    }
+    // mj_Euler
+#pragma unroll
+    for (int i = 0; i < 3; i++) { c.vel[i] += h*al[i]; c.vel[3+i] += h*aa[i]; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.pos[i] += h*c.vel[i];
+    {   // mju_quatIntegrate
+        T w[3] = { c.vel[3], c.vel[4], c.vel[5] };
+        const T nrm = tsqrt(dot(w, w));
+        if (nrm < T(1e-15)) { w[0] = T(1); w[1] = T(0); w[2] = T(0); }
+        else { const T rn = T(1)/nrm; w[0] *= rn; w[1] *= rn; w[2] *= rn; }
+        T sn, cs; tsincos<T>(T(0.5)*h*nrm, sn, cs);
+        quat_normalize(c.quat);
+        const T a = c.quat[0], b = c.quat[1], cc = c.quat[2], d = c.quat[3];
+        const T rw = cs, rx = w[0]*sn, ry = w[1]*sn, rz = w[2]*sn;
+        c.quat[0] = a*rw - b*rx - cc*ry - d*rz;
+        c.quat[1] = a*rx + b*rw + cc*rz - d*ry;
+        c.quat[2] = a*ry - b*rz + cc*rw + d*rx;
+        c.quat[3] = a*rz + b*ry - cc*rx + d*rw;
+    }
+}
+
+}  // namespace so100

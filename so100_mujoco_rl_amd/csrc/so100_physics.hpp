@@ -1,0 +1,516 @@
+// so100_physics.hpp -- per-env physics of the so100 scene, written for one GPU lane per env.
+//
+// What it computes is what MuJoCo's mj_step computes for this model:
+// forward kinematics, composite-rigid-body mass matrix, RNE bias force, position-servo actuation,
+// friction-loss / joint-limit / cube-floor constraint rows, a projected Gauss-Seidel solve of the
+// dual, semi-implicit Euler.  HOW it computes it is not MuJoCo's: the arm is a 6-link serial chain, so
+// everything runs in LINK coordinates with the joint axis a coordinate axis of the link frame
+// (Featherstone RNEA + CRBA), model constants are compile-time literals (so100_model_gen.h), the
+// 6x6 system is factorised in registers, and the constraint rows (all +-e_i on the arm) are solved in
+// joint space.  World-frame poses are only formed where the task layer reads them.
+//
+// Templated on the scalar T: float on the device; float/double host instantiations exist ONLY for the
+// CPU-side unit tests in tests/_hostcheck (never linked into libso100sim.so).
+#pragma once
+#include "so100_model_gen.h"
+
+#ifndef SO100_HD
+#if defined(__HIPCC__)
+#define SO100_HD __host__ __device__ __forceinline__
+#else
+#define SO100_HD inline
+#endif
+#endif
+
+namespace so100 {
+
+// physics option flags (include/so100_sim.h)
+enum : unsigned { F_FRICTIONLOSS = 1u, F_LIMITS = 2u, F_FLOOR = 4u, F_CUBE_PINNED = 8u };
+
+template <typename T> SO100_HD T tmin(T a, T b) { return a < b ? a : b; }
+template <typename T> SO100_HD T tmax(T a, T b) { return a > b ? a : b; }
+template <typename T> SO100_HD T tclamp(T x, T lo, T hi) { return tmin(tmax(x, lo), hi); }
+template <typename T> SO100_HD T tabs(T a) { return a < T(0) ? -a : a; }
+
+SO100_HD float  tsqrt(float x)  { return __builtin_sqrtf(x); }
+SO100_HD double tsqrt(double x) { return __builtin_sqrt(x); }
+SO100_HD float  tfloor(float x)  { return __builtin_floorf(x); }
+SO100_HD double tfloor(double x) { return __builtin_floor(x); }
+
+// sin and cos for |x| <= ~8 rad (joint angles are bounded by their limits; |x| < 3.5 in practice).
+// Cody-Waite reduction by pi/2 (3-term split) + minimax polynomials on [-pi/4, pi/4] (cephes sinf /
+// cosf coefficients; max error < 1 ulp in fp32).  Identical arithmetic on host and device.
+template <typename T> SO100_HD void tsincos(T x, T& s, T& c);
+template <> SO100_HD void tsincos<float>(float x, float& s, float& c) {
+    const float k = tfloor(x * 0.636619772367581343f + 0.5f);          // nearest multiple of pi/2
+    float r = __builtin_fmaf(k, -1.5703125f, x);
+    r = __builtin_fmaf(k, -4.837512969970703125e-4f, r);
+    r = __builtin_fmaf(k, -7.54978995489188e-8f, r);
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+    ps = __builtin_fmaf(ps * z, r, r);
+    float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+    pc = __builtin_fmaf(pc * z, z, __builtin_fmaf(z, -0.5f, 1.0f));
+    const int n = (int)k & 3;
+    const float ss = (n & 1) ? pc : ps, cc = (n & 1) ? ps : pc;
+    s = (n & 2) ? -ss : ss;
+    c = ((n + 1) & 2) ? -cc : cc;
+}
+template <> SO100_HD void tsincos<double>(double x, double& s, double& c) {
+    s = __builtin_sin(x); c = __builtin_cos(x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers (everything is fully unrolled; arrays live in registers)
+// ---------------------------------------------------------------------------------------------
+template <typename T> SO100_HD void cross(const T a[3], const T b[3], T r[3]) {
+    const T x = a[1]*b[2] - a[2]*b[1], y = a[2]*b[0] - a[0]*b[2], z = a[0]*b[1] - a[1]*b[0];
+    r[0] = x; r[1] = y; r[2] = z;
+}
+template <typename T> SO100_HD T dot(const T a[3], const T b[3]) { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+
+// rotation about coordinate axis A by (s,c): y = Rot x   and   y = Rot^T x
+template <int A, typename T> SO100_HD void rot_axis(const T x[3], T s, T c, T y[3]) {
+    constexpr int B = (A + 1) % 3, C = (A + 2) % 3;
+    const T xb = x[B], xc = x[C];
+    y[A] = x[A]; y[B] = c*xb - s*xc; y[C] = s*xb + c*xc;
+}
+template <int A, typename T> SO100_HD void rot_axis_T(const T x[3], T s, T c, T y[3]) {
+    constexpr int B = (A + 1) % 3, C = (A + 2) % 3;
+    const T xb = x[B], xc = x[C];
+    y[A] = x[A]; y[B] = c*xb + s*xc; y[C] = -s*xb + c*xc;
+}
+// constant link rotation C_K (child->parent) and its transpose
+template <int K, typename T> SO100_HD void cmat(const T x[3], T y[3]) {
+    const T x0 = x[0], x1 = x[1], x2 = x[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        y[i] = T(so100g::LINK_C[K][3*i])*x0 + T(so100g::LINK_C[K][3*i+1])*x1 + T(so100g::LINK_C[K][3*i+2])*x2;
+}
+template <int K, typename T> SO100_HD void cmat_T(const T x[3], T y[3]) {
+    const T x0 = x[0], x1 = x[1], x2 = x[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        y[i] = T(so100g::LINK_C[K][i])*x0 + T(so100g::LINK_C[K][3+i])*x1 + T(so100g::LINK_C[K][6+i])*x2;
+}
+// parent coords -> link K coords (E_K^T) and back (E_K), E_K = C_K Rot(axis_K, q_K)
+template <int K, typename T> SO100_HD void to_child(const T x[3], T s, T c, T y[3]) {
+    T t[3]; cmat_T<K>(x, t); rot_axis_T<so100g::LINK_AXIS[K]>(t, s, c, y);
+}
+template <int K, typename T> SO100_HD void to_parent(const T x[3], T s, T c, T y[3]) {
+    T t[3]; rot_axis<so100g::LINK_AXIS[K]>(x, s, c, t); cmat<K>(t, y);
+}
+
+// symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
+template <typename T> SO100_HD void sym_mul(const T I[6], const T v[3], T r[3]) {
+    const T x = I[0]*v[0] + I[3]*v[1] + I[4]*v[2];
+    const T y = I[3]*v[0] + I[1]*v[1] + I[5]*v[2];
+    const T z = I[4]*v[0] + I[5]*v[1] + I[2]*v[2];
+    r[0] = x; r[1] = y; r[2] = z;
+}
+SO100_HD constexpr int sym_idx(int i, int j) {
+    return i == j ? i : ((i + j == 1) ? 3 : ((i + j == 2) ? 4 : 5));
+}
+// B = R A R^T for a general 3x3 R (row-major) and symmetric A
+template <typename T> SO100_HD void sym_similarity(const T R[9], const T A[6], T Bm[6]) {
+    T t[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const T r0 = R[3*i], r1 = R[3*i+1], r2 = R[3*i+2];
+        t[3*i]   = r0*A[0] + r1*A[3] + r2*A[4];
+        t[3*i+1] = r0*A[3] + r1*A[1] + r2*A[5];
+        t[3*i+2] = r0*A[4] + r1*A[5] + r2*A[2];
+    }
+    Bm[0] = t[0]*R[0] + t[1]*R[1] + t[2]*R[2];
+    Bm[1] = t[3]*R[3] + t[4]*R[4] + t[5]*R[5];
+    Bm[2] = t[6]*R[6] + t[7]*R[7] + t[8]*R[8];
+    Bm[3] = t[0]*R[3] + t[1]*R[4] + t[2]*R[5];
+    Bm[4] = t[0]*R[6] + t[1]*R[7] + t[2]*R[8];
+    Bm[5] = t[3]*R[6] + t[4]*R[7] + t[5]*R[8];
+}
+// similarity by a rotation about coordinate axis A: B = Rot A Rot^T
+template <int AX, typename T> SO100_HD void sym_rot_axis(const T A[6], T s, T c, T Bm[6]) {
+    constexpr int B = (AX + 1) % 3, C = (AX + 2) % 3;
+    constexpr int iab = sym_idx(AX, B), iac = sym_idx(AX, C), ibc = sym_idx(B, C);
+    const T aab = A[iab], aac = A[iac], abb = A[B], acc = A[C], abc = A[ibc];
+    const T cc = c*c, ss = s*s, sc = s*c;
+    Bm[AX] = A[AX];
+    Bm[iab] = c*aab - s*aac;
+    Bm[iac] = s*aab + c*aac;
+    Bm[B] = cc*abb - T(2)*sc*abc + ss*acc;
+    Bm[C] = ss*abb + T(2)*sc*abc + cc*acc;
+    Bm[ibc] = sc*(abb - acc) + (cc - ss)*abc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// arm dynamics: M (packed lower triangle, armature included) and bias = C(q,v) + g(q)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct Arm {
+    T s[6], c[6];          // sin/cos of the joint angles
+    T M[21];               // M[i(i+1)/2 + j], j <= i
+    T bias[6];
+};
+
+template <int K, typename T> struct LinkFwd {            // RNEA forward step for link K
+    SO100_HD static void run(const T s[6], const T c[6], const T v[6], T w[3], T wd[3], T a[3],
+                             T f[6][3], T n[6][3]) {
+        constexpr int AX = so100g::LINK_AXIS[K];
+        const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
+        // acceleration of this link's origin, in parent coords: a + wd x p + w x (w x p)
+        T t1[3], t2[3], ao[3];
+        cross(wd, p, t1); cross(w, p, t2); cross(w, t2, t2);
+        ao[0] = a[0] + t1[0] + t2[0]; ao[1] = a[1] + t1[1] + t2[1]; ao[2] = a[2] + t1[2] + t2[2];
+        T wc[3], wdc[3];
+        to_child<K>(w, s[K], c[K], wc);
+        to_child<K>(wd, s[K], c[K], wdc);
+        to_child<K>(ao, s[K], c[K], a);
+        // wd_k = E^T wd_p + (E^T w_p) x (axis qd);  w_k = E^T w_p + axis qd
+        constexpr int B = (AX + 1) % 3, C = (AX + 2) % 3;
+        const T qd = v[K];
+        wdc[B] += wc[C]*qd; wdc[C] -= wc[B]*qd;
+        wc[AX] += qd;
+        w[0] = wc[0]; w[1] = wc[1]; w[2] = wc[2];
+        wd[0] = wdc[0]; wd[1] = wdc[1]; wd[2] = wdc[2];
+        // spatial force about the link origin:  f = m a + wd x h + w x (w x h),  n = Io wd + w x (Io w) + h x a
+        const T h[3] = { T(so100g::LINK_H[K][0]), T(so100g::LINK_H[K][1]), T(so100g::LINK_H[K][2]) };
+        const T Io[6] = { T(so100g::LINK_IORG[K][0]), T(so100g::LINK_IORG[K][1]), T(so100g::LINK_IORG[K][2]),
+                          T(so100g::LINK_IORG[K][3]), T(so100g::LINK_IORG[K][4]), T(so100g::LINK_IORG[K][5]) };
+        const T m = T(so100g::LINK_MASS[K]);
+        T u1[3], u2[3], Iw[3];
+        cross(wd, h, u1); cross(w, h, u2); cross(w, u2, u2);
+        f[K][0] = m*a[0] + u1[0] + u2[0]; f[K][1] = m*a[1] + u1[1] + u2[1]; f[K][2] = m*a[2] + u1[2] + u2[2];
+        sym_mul(Io, wd, u1); sym_mul(Io, w, Iw); cross(w, Iw, u2);
+        T u3[3]; cross(h, a, u3);
+        n[K][0] = u1[0] + u2[0] + u3[0]; n[K][1] = u1[1] + u2[1] + u3[1]; n[K][2] = u1[2] + u2[2] + u3[2];
+    }
+};
+
+template <int K, typename T> struct LinkBwd {            // RNEA backward step: project, pass to parent
+    SO100_HD static void run(const T s[6], const T c[6], T f[6][3], T n[6][3], T bias[6]) {
+        bias[K] = n[K][so100g::LINK_AXIS[K]];
+        if constexpr (K > 0) {
+            const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
+            T fp[3], np[3], t[3];
+            to_parent<K>(f[K], s[K], c[K], fp);
+            to_parent<K>(n[K], s[K], c[K], np);
+            cross(p, fp, t);
+#pragma unroll
+            for (int i = 0; i < 3; i++) { f[K-1][i] += fp[i]; n[K-1][i] += np[i] + t[i]; }
+        }
+    }
+};
+
+// composite inertia of the subtree rooted at link K, in link-K coords about the link-K origin
+template <typename T> struct Composite { T m, h[3], I[6]; };
+
+template <int K, typename T> struct LinkCrb {
+    // add link K's composite (already complete) into its parent's, then emit column K of M
+    SO100_HD static void run(const T s[6], const T c[6], Composite<T> cmp[6], T M[21]) {
+        constexpr int AX = so100g::LINK_AXIS[K];
+        // ---- column K: unit acceleration about axis K of the composite body
+        {
+            constexpr int B = (AX + 1) % 3, C = (AX + 2) % 3;
+            T f[3], n[3];
+            // f = axis x h,  n = Ic[:,axis]
+            f[AX] = T(0); f[B] = -cmp[K].h[C]; f[C] = cmp[K].h[B];
+            n[0] = cmp[K].I[sym_idx(0, AX)]; n[1] = cmp[K].I[sym_idx(1, AX)]; n[2] = cmp[K].I[sym_idx(2, AX)];
+            M[K*(K+1)/2 + K] = n[AX] + T(so100g::ARMATURE);
+            walk<K>(s, c, f, n, M);
+        }
+        // ---- accumulate into the parent
+        if constexpr (K > 0) {
+            const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
+            T hp[3], Ir[6], Ip[6];
+            to_parent<K>(cmp[K].h, s[K], c[K], hp);
+            sym_rot_axis<AX>(cmp[K].I, s[K], c[K], Ir);
+            T Cm[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Cm[i] = T(so100g::LINK_C[K][i]);
+            sym_similarity(Cm, Ir, Ip);
+            const T m = cmp[K].m;
+            const T pp = dot(p, p), ph = dot(p, hp);
+            const T dg = m*pp + T(2)*ph;
+            Composite<T>& P = cmp[K-1];
+            P.I[0] += Ip[0] + dg - m*p[0]*p[0] - T(2)*p[0]*hp[0];
+            P.I[1] += Ip[1] + dg - m*p[1]*p[1] - T(2)*p[1]*hp[1];
+            P.I[2] += Ip[2] + dg - m*p[2]*p[2] - T(2)*p[2]*hp[2];
+            P.I[3] += Ip[3] - m*p[0]*p[1] - p[0]*hp[1] - hp[0]*p[1];
+            P.I[4] += Ip[4] - m*p[0]*p[2] - p[0]*hp[2] - hp[0]*p[2];
+            P.I[5] += Ip[5] - m*p[1]*p[2] - p[1]*hp[2] - hp[1]*p[2];
+            P.h[0] += hp[0] + m*p[0]; P.h[1] += hp[1] + m*p[1]; P.h[2] += hp[2] + m*p[2];
+            P.m += m;
+        }
+    }
+    // carry (f, n) from frame J+1 to frame J for J = K-1 .. 0 and read M[K][J]
+    template <int J1> SO100_HD static void walk(const T s[6], const T c[6], T f[3], T n[3], T M[21]) {
+        if constexpr (J1 > 0) {
+            const T p[3] = { T(so100g::LINK_P[J1][0]), T(so100g::LINK_P[J1][1]), T(so100g::LINK_P[J1][2]) };
+            T fp[3], np[3], t[3];
+            to_parent<J1>(f, s[J1], c[J1], fp);
+            to_parent<J1>(n, s[J1], c[J1], np);
+            cross(p, fp, t);
+            f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
+            n[0] = np[0] + t[0]; n[1] = np[1] + t[1]; n[2] = np[2] + t[2];
+            M[K*(K+1)/2 + (J1-1)] = n[so100g::LINK_AXIS[J1-1]];
+            walk<J1-1>(s, c, f, n, M);
+        }
+    }
+};
+
+template <typename T> SO100_HD void arm_dynamics(const T q[6], const T v[6], Arm<T>& A) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) tsincos<T>(q[k], A.s[k], A.c[k]);
+    // RNEA (bias): base at rest, gravity folded in as a base acceleration of +g along world z
+    T w[3] = { T(0), T(0), T(0) }, wd[3] = { T(0), T(0), T(0) }, a[3] = { T(0), T(0), T(so100g::GRAVITY) };
+    T f[6][3], n[6][3];
+    LinkFwd<0, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkFwd<1, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkFwd<2, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkFwd<3, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkFwd<4, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkFwd<5, T>::run(A.s, A.c, v, w, wd, a, f, n);
+    LinkBwd<5, T>::run(A.s, A.c, f, n, A.bias);
+    LinkBwd<4, T>::run(A.s, A.c, f, n, A.bias);
+    LinkBwd<3, T>::run(A.s, A.c, f, n, A.bias);
+    LinkBwd<2, T>::run(A.s, A.c, f, n, A.bias);
+    LinkBwd<1, T>::run(A.s, A.c, f, n, A.bias);
+    LinkBwd<0, T>::run(A.s, A.c, f, n, A.bias);
+    // CRBA
+    Composite<T> cmp[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        cmp[k].m = T(so100g::LINK_MASS[k]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) cmp[k].h[i] = T(so100g::LINK_H[k][i]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) cmp[k].I[i] = T(so100g::LINK_IORG[k][i]);
+    }
+    LinkCrb<5, T>::run(A.s, A.c, cmp, A.M);
+    LinkCrb<4, T>::run(A.s, A.c, cmp, A.M);
+    LinkCrb<3, T>::run(A.s, A.c, cmp, A.M);
+    LinkCrb<2, T>::run(A.s, A.c, cmp, A.M);
+    LinkCrb<1, T>::run(A.s, A.c, cmp, A.M);
+    LinkCrb<0, T>::run(A.s, A.c, cmp, A.M);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 6x6 SPD: LDL^T in place on the packed lower triangle, then the explicit inverse
+// ---------------------------------------------------------------------------------------------
+#define SO100_TRI(i, j) ((i)*((i)+1)/2 + (j))
+template <typename T> SO100_HD void ldl6(T M[21], T Dinv[6]) {     // M <- L (unit lower, strict part), D on the diagonal
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        T d = M[SO100_TRI(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= M[SO100_TRI(j, k)]*M[SO100_TRI(j, k)]*M[SO100_TRI(k, k)];
+        M[SO100_TRI(j, j)] = d;
+        Dinv[j] = T(1)/d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            T t = M[SO100_TRI(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= M[SO100_TRI(i, k)]*M[SO100_TRI(j, k)]*M[SO100_TRI(k, k)];
+            M[SO100_TRI(i, j)] = t*Dinv[j];
+        }
+    }
+}
+template <typename T> SO100_HD void ldl6_solve(const T L[21], const T Dinv[6], T x[6]) {
+#pragma unroll
+    for (int i = 1; i < 6; i++)
+#pragma unroll
+        for (int k = 0; k < i; k++) x[i] -= L[SO100_TRI(i, k)]*x[k];
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] *= Dinv[i];
+#pragma unroll
+    for (int i = 4; i >= 0; i--)
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) x[i] -= L[SO100_TRI(k, i)]*x[k];
+}
+// Minv (packed lower) = L^-T D^-1 L^-1
+template <typename T> SO100_HD void ldl6_inverse(const T L[21], const T Dinv[6], T Minv[21]) {
+    T Li[21];                                  // Li = L^-1 (unit lower)
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        Li[SO100_TRI(j, j)] = T(1);
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            T t = -L[SO100_TRI(i, j)];
+#pragma unroll
+            for (int k = j + 1; k < i; k++) t -= L[SO100_TRI(i, k)]*Li[SO100_TRI(k, j)];
+            Li[SO100_TRI(i, j)] = t;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            T t = T(0);
+#pragma unroll
+            for (int k = i; k < 6; k++) t += Li[SO100_TRI(k, i)]*Dinv[k]*Li[SO100_TRI(k, j)];
+            Minv[SO100_TRI(i, j)] = t;
+        }
+}
+template <typename T> SO100_HD T sym6(const T A[21], int i, int j) { return i >= j ? A[SO100_TRI(i, j)] : A[SO100_TRI(j, i)]; }
+
+// impedance d(r) of the default solimp (0.9, 0.95, 0.001, 0.5, 2), r = |pos - margin|
+template <typename T> SO100_HD T impedance(T r) {
+    const T x = r * T(1.0/so100g::SOLIMP_WIDTH);
+    const T d0 = T(so100g::SOLIMP_D0), dm = T(so100g::SOLIMP_DMAX);
+    if (x >= T(1)) return dm;
+    if (x <= T(0)) return d0;
+    const T y = x <= T(0.5) ? T(2)*x*x : T(1) - T(2)*(T(1) - x)*(T(1) - x);
+    return d0 + y*(dm - d0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// one arm substep: forward dynamics + constraint solve + semi-implicit Euler
+//   q, v        : joint positions / velocities (updated)
+//   ctrl        : servo targets
+//   ff, fl      : friction-loss / limit row forces of the previous substep (PGS warm start; updated)
+//   iters       : PGS sweeps
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+SO100_HD void arm_substep(T q[6], T v[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+    arm_dynamics(q, v, A);
+    // mj_fwdActuation: position servo kp (u - q) - kv qd, u clamped to ctrlrange, force to forcerange
+    T tau[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const T u = tclamp(ctrl[i], T(-so100g::ACT_CTRL), T(so100g::ACT_CTRL));
+        T f = T(so100g::ACT_KP)*u - T(so100g::ACT_KP)*q[i] - T(so100g::ACT_KV[i])*v[i];
+        f = tclamp(f, T(-so100g::ACT_FORCE), T(so100g::ACT_FORCE));
+        tau[i] = f - A.bias[i];
+    }
+    T Dinv[6], acc[6];
+    ldl6(A.M, Dinv);
+    const bool constrained = (flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u;
+    if (!constrained) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = tau[i];
+        ldl6_solve(A.M, Dinv, acc);
+    } else {
+        T Minv[21];
+        ldl6_inverse(A.M, Dinv, Minv);
+        T a0[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T t = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tau[j];
+            a0[i] = t;
+        }
+        // rows: friction (J = e_i, |f| <= frictionloss) then limits (J = sg_i e_i, f >= 0)
+        const T Bd = T(so100g::SOLREF_B), Kd = T(so100g::SOLREF_K);
+        T bf[6], Rf[6], bl[6], Rl[6], sg[6], fmax_[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const bool fr = (flags & F_FRICTIONLOSS) != 0u;
+            Rf[i] = T((1.0 - so100g::SOLIMP_D0)/so100g::SOLIMP_D0 * so100g::DOF_INVWEIGHT0[i]);
+            bf[i] = a0[i] + Bd*v[i];                          // J a0 - aref, aref = -B v
+            fmax_[i] = fr ? T(so100g::FRICTIONLOSS) : T(0);
+            if (!fr) ff[i] = T(0);
+            const T dlo = q[i] - T(so100g::JNT_RANGE[i][0]), dhi = T(so100g::JNT_RANGE[i][1]) - q[i];
+            const bool lo = dlo < T(0), hi = dhi < T(0);
+            const bool act = (flags & F_LIMITS) != 0u && (lo || hi);
+            const T dist = lo ? dlo : dhi;
+            sg[i] = lo ? T(1) : T(-1);
+            const T imp = impedance(tabs(dist));
+            Rl[i] = (T(1) - imp)/imp * T(so100g::DOF_INVWEIGHT0[i]);
+            bl[i] = sg[i]*a0[i] + Bd*sg[i]*v[i] + Kd*imp*dist;
+            if (!act) { fl[i] = T(0); sg[i] = T(0); }          // inactive row: force pinned at 0
+            else fl[i] = tmax(fl[i], T(0));
+        }
+        // Block Gauss-Seidel over JOINTS: the friction row and the limit row of one joint are collinear
+        // (J = e_i and sg_i e_i), so scalar PGS crawls when both are active (rate a^2/((a+Rf)(a+Rl)) ~ 0.84).
+        // Each joint's 2-row box QP  min 1/2 [f l] [[a+Rf, sg a],[sg a, a+Rl]] [f l]' + [f l].[cf cl],
+        // |f| <= fmax, l >= 0  is solved exactly by enumerating its active sets; the coupling between joints
+        // (armature-dominated M => nearly diagonal Minv) then converges in a few sweeps.
+        T tq[6];                                              // joint-space constraint torque J^T f
+#pragma unroll
+        for (int i = 0; i < 6; i++) tq[i] = ff[i] + sg[i]*fl[i];
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                T w = T(0);
+#pragma unroll
+                for (int j = 0; j < 6; j++) w += sym6(Minv, i, j)*tq[j];
+                const T a = sym6(Minv, i, i);
+                const T wo = w - a*tq[i];                     // contribution of the other joints
+                const T cf = bf[i] + wo, cl = bl[i] + sg[i]*wo;
+                const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a, F = fmax_[i];
+                // (1) limit row inactive
+                const T f1 = tclamp(-cf/Af, -F, F);
+                const bool ok1 = (sg[i] == T(0)) || (cl + cx*f1 >= T(0));
+                // (2) both interior
+                const T det = Af*Al - cx*cx;
+                const T f2 = (cx*cl - cf*Al)/det, l2 = (cx*cf - Af*cl)/det;
+                const bool ok2 = tabs(f2) <= F && l2 >= T(0);
+                // (3) friction saturated, limit active
+                const T lp = tmax(-(cl + cx*F)/Al, T(0)), lm = tmax(-(cl - cx*F)/Al, T(0));
+                const bool okp = cf + Af*F + cx*lp <= T(0);
+                const T f3 = okp ? F : -F, l3 = okp ? lp : lm;
+                const T fn = ok1 ? f1 : (ok2 ? f2 : f3);
+                const T ln = ok1 ? T(0) : (ok2 ? l2 : l3);
+                ff[i] = fn; fl[i] = ln;
+                tq[i] = fn + sg[i]*ln;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T t = a0[i];
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tq[j];
+            acc[i] = t;
+        }
+    }
+    const T h = T(so100g::TIMESTEP);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { v[i] += h*acc[i]; q[i] += h*v[i]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// world-frame poses the task layer reads (computed from the sin/cos of the substep they belong to)
+// ---------------------------------------------------------------------------------------------
+template <typename T> struct TaskPoses {
+    T wrist[3];            // xpos of Wrist_Pitch_Roll (link 3)
+    T jaw_pos[3];          // xpos of Fixed_Jaw (link 4)
+    T jaw_mat[9];          // xmat of Fixed_Jaw, row-major
+    T cam_pos[3], cam_mat[9];
+};
+template <int K, typename T> SO100_HD void fk_link(const T s[6], const T c[6], T pos[3], T R[9]) {
+    // pos += R p_K ; R <- R C_K Rot_K
+    const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
+#pragma unroll
+    for (int i = 0; i < 3; i++) pos[i] += R[3*i]*p[0] + R[3*i+1]*p[1] + R[3*i+2]*p[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {          // each row r of R: r <- (r C) Rot  == to_child applied to the row
+        T row[3] = { R[3*i], R[3*i+1], R[3*i+2] }, out[3];
+        to_child<K>(row, s[K], c[K], out);
+        R[3*i] = out[0]; R[3*i+1] = out[1]; R[3*i+2] = out[2];
+    }
+}
+template <typename T> SO100_HD void task_poses(const T s[6], const T c[6], bool want_cam, TaskPoses<T>& P) {
+    T pos[3] = { T(0), T(0), T(0) };
+    T R[9] = { T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1) };
+    fk_link<0>(s, c, pos, R); fk_link<1>(s, c, pos, R); fk_link<2>(s, c, pos, R);
+    fk_link<3>(s, c, pos, R);
+    P.wrist[0] = pos[0]; P.wrist[1] = pos[1]; P.wrist[2] = pos[2];
+    fk_link<4>(s, c, pos, R);
+#pragma unroll
+    for (int i = 0; i < 3; i++) P.jaw_pos[i] = pos[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) P.jaw_mat[i] = R[i];
+    if (want_cam) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            P.cam_pos[i] = pos[i] + R[3*i]*T(so100g::CAM_P[0]) + R[3*i+1]*T(so100g::CAM_P[1]) + R[3*i+2]*T(so100g::CAM_P[2]);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                P.cam_mat[3*i+j] = R[3*i]*T(so100g::CAM_R[j]) + R[3*i+1]*T(so100g::CAM_R[3+j]) + R[3*i+2]*T(so100g::CAM_R[6+j]);
+        }
+    }
+}
+
+}  // namespace so100

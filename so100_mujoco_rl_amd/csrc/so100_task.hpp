@@ -1,0 +1,404 @@
+// so100_task.hpp -- the reference's task layer (reward / obs / ctrl / reset / curriculum / reprojection)
+// for one env held in registers, fp32.  Each function cites the reference lines it restates
+// ("ref:" = /root/reference/src/so100_mujoco_rl/envs/).  Semantics that parity depends on (SURVEY.md
+// section 8a quirks Q1-Q7) are reproduced on purpose:
+//   Q1 stale kinematics: poses read by obs/reward are those of the START of the last substep,
+//   Q2 the reward of step t is computed from the state left by step t-1,
+//   Q3 ctrl is relative to the measured angle (Env01/02) or to the commanded angle (Env03-05),
+//   Q4 Env05 step observations scale the image centre by 5, reset observations do not,
+//   after reset all poses are zero (mj_resetData) until the first step.
+#pragma once
+#include "so100_physics.hpp"
+#include "so100_cube.hpp"
+#include <stdint.h>
+
+namespace so100 {
+
+struct SimParams {
+    int32_t  n;
+    uint32_t flags;
+    int32_t  solver_iters, contact_iters, frame_skip, max_episode_steps;
+    uint32_t seed_lo, seed_hi, env_id_offset;
+};
+
+// ---- per-env persistent state ---------------------------------------------------------------------
+// bits of EnvState::bits
+enum : int { B_HAS_PREV = 1, B_HAVE_BLOCK = 2, B_HAVE_LAST_BLOCK = 4, B_HAVE_CENTER = 8, B_HAVE_ANGVEL = 16,
+             B_BLOCK_UPDATED = 32, B_ANTIGRAV = 64 };
+
+struct EnvState {
+    float q[6];                 // arm joint angles                      (qpos[0:6])
+    Cube<float> cube;           // pos, quat, vel, Newton warm start     (qpos[6:13], qvel[6:12])
+    float v[6];                 // arm joint velocities                  (qvel[0:6])
+    float ff[6], fl[6];         // friction-loss / limit row forces (warm start)
+    float ee[3], wrist_z, cx[3];// stale end effector, wrist height, cube xpos (Q1)
+    int   nsub, elapsed, bits, rngc;
+    float epret; int eplen;
+    float bp[3], lbp[3];        // Env02 sampled block positions (ref: env02_v1.py:64-68)
+    float cmd[6];               // Env03-05 commanded angles (ref: env_base_02.py:85-86)
+    float lc[2]; int lost;      // last detected centre, lost counter (ref: env03_v1.py:152-164)
+    float tgt[3], tdt, ttime;   // cube target, dwell, time of last retarget (ref: env03_v1.py:77-93)
+    float av[6];                // last "angular velocities" (ref: env_base_01.py:165-178)
+};
+
+// The [field][N] state matrix.  X(name, member, kind, group): kind f = float, i = int32;
+// group 0 = all env kinds, 1 = Env01/02, 2 = Env02, 3 = Env03-05.
+#define SO100_STATE_FIELDS(X) \
+    X(q0, q[0], f, 0) X(q1, q[1], f, 0) X(q2, q[2], f, 0) X(q3, q[3], f, 0) X(q4, q[4], f, 0) X(q5, q[5], f, 0) \
+    X(cube_x, cube.pos[0], f, 0) X(cube_y, cube.pos[1], f, 0) X(cube_z, cube.pos[2], f, 0) \
+    X(cube_qw, cube.quat[0], f, 0) X(cube_qx, cube.quat[1], f, 0) X(cube_qy, cube.quat[2], f, 0) X(cube_qz, cube.quat[3], f, 0) \
+    X(v0, v[0], f, 0) X(v1, v[1], f, 0) X(v2, v[2], f, 0) X(v3, v[3], f, 0) X(v4, v[4], f, 0) X(v5, v[5], f, 0) \
+    X(cube_vx, cube.vel[0], f, 0) X(cube_vy, cube.vel[1], f, 0) X(cube_vz, cube.vel[2], f, 0) \
+    X(cube_wx, cube.vel[3], f, 0) X(cube_wy, cube.vel[4], f, 0) X(cube_wz, cube.vel[5], f, 0) \
+    X(ff0, ff[0], f, 0) X(ff1, ff[1], f, 0) X(ff2, ff[2], f, 0) X(ff3, ff[3], f, 0) X(ff4, ff[4], f, 0) X(ff5, ff[5], f, 0) \
+    X(fl0, fl[0], f, 0) X(fl1, fl[1], f, 0) X(fl2, fl[2], f, 0) X(fl3, fl[3], f, 0) X(fl4, fl[4], f, 0) X(fl5, fl[5], f, 0) \
+    X(cw0, cube.warm[0], f, 0) X(cw1, cube.warm[1], f, 0) X(cw2, cube.warm[2], f, 0) \
+    X(cw3, cube.warm[3], f, 0) X(cw4, cube.warm[4], f, 0) X(cw5, cube.warm[5], f, 0) \
+    X(substeps, nsub, i, 0) X(elapsed_steps, elapsed, i, 0) X(bits, bits, i, 0) X(rng_counter, rngc, i, 0) \
+    X(episode_return, epret, f, 0) X(episode_length, eplen, i, 0) \
+    X(ee_x, ee[0], f, 1) X(ee_y, ee[1], f, 1) X(ee_z, ee[2], f, 1) X(wrist_z, wrist_z, f, 1) \
+    X(cx_x, cx[0], f, 1) X(cx_y, cx[1], f, 1) X(cx_z, cx[2], f, 1) \
+    X(bp_x, bp[0], f, 2) X(bp_y, bp[1], f, 2) X(bp_z, bp[2], f, 2) X(lbp_x, lbp[0], f, 2) X(lbp_y, lbp[1], f, 2) X(lbp_z, lbp[2], f, 2) \
+    X(cmd0, cmd[0], f, 3) X(cmd1, cmd[1], f, 3) X(cmd2, cmd[2], f, 3) X(cmd3, cmd[3], f, 3) X(cmd4, cmd[4], f, 3) X(cmd5, cmd[5], f, 3) \
+    X(lc_x, lc[0], f, 3) X(lc_y, lc[1], f, 3) X(lost_count, lost, i, 3) \
+    X(tgt_x, tgt[0], f, 3) X(tgt_y, tgt[1], f, 3) X(tgt_z, tgt[2], f, 3) X(target_dt, tdt, f, 3) X(target_time, ttime, f, 3) \
+    X(av0, av[0], f, 3) X(av1, av[1], f, 3) X(av2, av[2], f, 3) X(av3, av[3], f, 3) X(av4, av[4], f, 3) X(av5, av[5], f, 3)
+
+enum StateField : int {
+#define X(name, member, kind, group) SF_##name,
+    SO100_STATE_FIELDS(X)
+#undef X
+    SF_COUNT
+};
+constexpr int SF_QPOS0 = SF_q0, SF_QVEL0 = SF_v0;       // 13 qpos rows then 12 qvel rows, contiguous
+
+template <int KIND> SO100_HD constexpr bool uses_group(int g) {
+    return g == 0 || (g == 1 && KIND <= 2) || (g == 2 && KIND == 2) || (g == 3 && KIND >= 3);
+}
+template <int KIND> SO100_HD constexpr int obs_dim() { return KIND <= 2 ? 15 : 8; }
+
+// ---- constants of the task layer --------------------------------------------------------------------
+#define SO100_PI_F 3.14159265358979323846f
+static constexpr float JOINT_STEP_SCALE = 0.075f;                                  // ref: utils.py:9
+static constexpr float REST_POSITION[6]  = { 0.0f, -3.141f, 3.117f, 1.0f, 0.0f, 0.0f };   // ref: utils.py:11
+static constexpr float START_POSITION[6] = { 0.0f, -2.04f, 1.19f, 1.5f, -1.58f, 0.5f };   // ref: env03_v1.py:10
+static constexpr float SPACE_START[2][3]  = { {-0.05f, -0.4f, 0.01f}, {0.05f, -0.3f, 0.01f} };   // ref: env03_v1.py:13-16
+static constexpr float SPACE_END_03[2][3] = { {-0.35f, -0.45f, 0.01f}, {0.35f, -0.25f, 0.01f} }; // ref: env03_v1.py:17-20
+static constexpr float SPACE_END_05[2][3] = { {-0.45f, -0.45f, 0.01f}, {0.45f, -0.25f, 0.5f} };  // ref: env05_v1.py:17-20
+// VALID_START_POSITIONS (ref: utils.py:13-50, 36 recorded poses) is indexed at run time, so it is passed as a
+// pointer to a [36][6] float table (device memory in the kernel; csrc/so100_start_positions.inc on the host).
+
+// ---- Philox4x32-10, same stream as oracle/so100_oracle.c ---------------------------------------------
+SO100_HD uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+SO100_HD void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t h0 = mulhi32(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const uint32_t h1 = mulhi32(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+SO100_HD void draw8(const SimParams& p, uint32_t env_gid, uint32_t counter, int phase, const float* inject, float u[8]) {
+    if (inject) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) u[i] = inject[8*phase + i];
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        uint32_t r[4];
+        philox4x32(env_gid, counter, (uint32_t)(2*phase + b), 0u, p.seed_lo, p.seed_hi, r);
+#pragma unroll
+        for (int i = 0; i < 4; i++) u[4*b + i] = (float)(r[i] >> 8) * (1.0f/16777216.0f);
+    }
+}
+
+// ---- pure task functions -----------------------------------------------------------------------------
+SO100_HD float joint_penalty(float a, float lo, float hi) {                // ref: env_base_01.py:153-163
+    const float lt = lo + 0.05f*(hi - lo), ut = hi - 0.05f*(hi - lo);
+    float pen = 0.0f;
+    if (a < lt) pen -= (lt - a)*10.0f;
+    else if (a > ut) pen -= (a - ut)*10.0f;
+    return pen;
+}
+SO100_HD float joint_reward(const float q[6]) {                            // ref: env_base_01.py:144-151
+    float r = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) r += joint_penalty(q[i], (float)so100g::JNT_RANGE[i][0], (float)so100g::JNT_RANGE[i][1]);
+    return r;
+}
+SO100_HD float reward_base(const float q[6], const float block[3], const float ee[3], float wrist_z, bool has_prev) {
+    // ref: env_base_01.py:180-239
+    float reward = 0.0f;
+    const float dx = block[0] - ee[0], dy = block[1] - ee[1], dz = block[2] - ee[2];
+    const float distance = tsqrt(dx*dx + dy*dy + dz*dz);
+    if (block[1] < -0.1f) {
+        const float pitch = q[1];
+        if (has_prev && pitch < -0.7f*SO100_PI_F) reward += (pitch + 0.7f*SO100_PI_F)*0.7f;
+    }
+    if (has_prev && ee[2] < 0.02f) reward += (ee[2] - 0.02f)*20.0f;
+    if (has_prev && wrist_z < 0.08f) reward += tclamp((wrist_z - 0.08f)*10.0f, -0.8f, 0.8f);
+    reward += tmin(-distance + 0.02f, 0.0f)*0.5f;
+    reward += joint_reward(q);
+    return reward;
+}
+// pinhole reprojection of the cube into the end-point camera; ref: env_base_02.py:88-127.
+// Returns false for "None" (NaN or outside the 1080 x 1920 frame); no z-sign test, like the reference.
+SO100_HD bool project(const float cam_pos[3], const float cam_mat[9], const float p[3], int& u_out, int& v_out) {
+    const float r0 = p[0] - cam_pos[0], r1 = p[1] - cam_pos[1], r2 = p[2] - cam_pos[2];
+    const float x = cam_mat[0]*r0 + cam_mat[3]*r1 + cam_mat[6]*r2;
+    const float y = cam_mat[1]*r0 + cam_mat[4]*r1 + cam_mat[7]*r2;
+    const float z = cam_mat[2]*r0 + cam_mat[5]*r1 + cam_mat[8]*r2;
+    const float f = 554.25625842204073f;                       // 0.5 * 1920 / tan(120 deg / 2)
+    const float u = f*x/z + 540.0f, v = f*y/z + 960.0f;
+    if (u != u || v != v) return false;
+    if (!(tabs(u) < 2.0e9f) || !(tabs(v) < 2.0e9f)) return false;   // int(inf) raises in Python: treated as None
+    const int iu = (int)u, iv = (int)v;                        // truncation toward zero, like int()
+    if (iu < 0 || iu >= 1080 || iv < 0 || iv >= 1920) return false;
+    u_out = 1080 - iu; v_out = 1920 - iv;
+    return true;
+}
+
+SO100_HD void set_random_block_position(EnvState& e, int kind, float dlo, const float u[8]) {
+    // ref: env01_v1.py:45-52 (dlo 0.18), env02_v1.py:52-68 (dlo 0.22); u[1] is the discarded draw
+    const float dist = dlo + (0.42f - dlo)*u[0];
+    const float theta = -0.5f*SO100_PI_F + (-0.25f*SO100_PI_F + (0.5f*SO100_PI_F)*u[2]);
+    float s, c; tsincos<float>(theta, s, c);
+    const float p[3] = { dist*c, dist*s, 0.0f };
+    e.cube.pos[0] = p[0]; e.cube.pos[1] = p[1]; e.cube.pos[2] = p[2];
+    if (kind == 2) {
+        if (!(e.bits & B_HAVE_LAST_BLOCK)) { e.lbp[0] = p[0]; e.lbp[1] = p[1]; e.lbp[2] = p[2]; e.bits |= B_HAVE_LAST_BLOCK; }
+        else { e.lbp[0] = e.bp[0]; e.lbp[1] = e.bp[1]; e.lbp[2] = e.bp[2]; }
+        e.bp[0] = p[0]; e.bp[1] = p[1]; e.bp[2] = p[2]; e.bits |= B_HAVE_BLOCK;
+    }
+}
+
+template <int KIND> SO100_HD void set_initial_values_03(EnvState& e) {     // ref: env03_v1.py:35-57, env04_v1.py:25-46
+#pragma unroll
+    for (int i = 0; i < 6; i++) e.cmd[i] = START_POSITION[i];
+    if (KIND == 4) e.bits |= B_HAVE_CENTER; else e.bits &= ~B_HAVE_CENTER;
+    e.lc[0] = e.lc[1] = -1.0f; e.lost = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) e.tgt[i] = (SPACE_START[0][i] + SPACE_START[1][i]) / 2;
+    e.tdt = 0.01f; e.ttime = 0.0f;
+    e.bits &= ~B_BLOCK_UPDATED;
+}
+
+// first-time initialisation of a fresh handle (EnvNN.__init__)
+template <int KIND> SO100_HD void env_init(EnvState& e) {
+    e = EnvState{};
+    e.cube.quat[0] = 1.0f;
+    if (KIND >= 3) {                                                       // ref: env_base_02.py:32,51
+        set_initial_values_03<KIND>(e);
+        e.cube.pos[0] = e.tgt[0]; e.cube.pos[1] = e.tgt[1]; e.cube.pos[2] = e.tgt[2];
+    }
+}
+
+// MujocoEnv.reset -> mj_resetData -> reset_model(); u = reset-phase uniforms
+template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const float* start_tab, float* obs) {
+    // mj_resetData: qpos = qpos0, everything else (velocities, warm starts, applied forces, time, POSES) zero
+#pragma unroll
+    for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; }
+    e.cube.pos[0] = e.cube.pos[1] = e.cube.pos[2] = 0.0f;
+    e.cube.quat[0] = 1.0f; e.cube.quat[1] = e.cube.quat[2] = e.cube.quat[3] = 0.0f;
+    e.ee[0] = e.ee[1] = e.ee[2] = 0.0f; e.wrist_z = 0.0f; e.cx[0] = e.cx[1] = e.cx[2] = 0.0f;
+    e.nsub = 0; e.bits &= ~B_ANTIGRAV;
+    e.elapsed = 0; e.epret = 0.0f; e.eplen = 0;
+    if (KIND == 1) {                                                       // ref: env01_v1.py:39-63
+        set_random_block_position(e, 1, 0.18f, u);
+        int idx = (int)(u[3]*36.0f); idx = idx > 35 ? 35 : idx;
+#pragma unroll
+        for (int i = 0; i < 5; i++) e.q[i] = start_tab[6*idx + i];                             // Jaw skipped (:58-59)
+    } else if (KIND == 2) {                                                // ref: env02_v1.py:70-81
+        set_random_block_position(e, 2, 0.22f, u);
+#pragma unroll
+        for (int i = 0; i < 6; i++) e.q[i] = REST_POSITION[i];
+    } else {                                                               // ref: env03_v1.py:203-215
+        set_initial_values_03<KIND>(e);
+        e.cube.pos[0] = e.tgt[0]; e.cube.pos[1] = e.tgt[1]; e.cube.pos[2] = e.tgt[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) e.q[i] = START_POSITION[i];
+    }
+    if (KIND <= 2) {                                                       // ref: env_base_01.py:241-270, all poses zero (Q1)
+#pragma unroll
+        for (int i = 0; i < 6; i++) obs[i] = e.q[i];
+#pragma unroll
+        for (int i = 6; i < 15; i++) obs[i] = 0.0f;
+    } else {                                                               // ref: env05_v1.py:32-75: camera pose zero => NaN => None
+#pragma unroll
+        for (int i = 0; i < 6; i++) obs[i] = e.cmd[i];
+        obs[6] = -1.0f; obs[7] = -1.0f;
+    }
+}
+
+// 16 physics substeps; leaves the stale poses of the LAST substep in P / cube_stale
+SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams& p, bool want_cam,
+                               TaskPoses<float>& P, float cube_stale[3]) {
+    Arm<float> A;
+    const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
+#pragma unroll 1
+    for (int s = 0; s < p.frame_skip; s++) {
+        cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
+        arm_substep<float>(e.q, e.v, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+        cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
+    }
+    e.nsub += p.frame_skip;
+    task_poses<float>(A.s, A.c, want_cam, P);      // sin/cos of the angles the last substep STARTED from
+}
+
+// One EnvNN.step.  a = action, u = step-phase uniforms.  Returns reward; sets term; fills obs.
+template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const float u[8], const SimParams& p,
+                                             float* obs, bool& term) {
+    term = false;
+    float reward;
+    TaskPoses<float> P;
+    float cstale[3];
+    if (KIND <= 2) {
+        // ref: env01_v1.py:15-37 / env02_v1.py:18-50
+        reward = reward_base(e.q, e.cx, e.ee, e.wrist_z, (e.bits & B_HAS_PREV) != 0);
+        e.bits |= B_HAS_PREV;
+        float ctrl[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) ctrl[i] = e.q[i] + a[i]*JOINT_STEP_SCALE;
+        if (KIND == 2) {
+            const float dx = e.cx[0] - e.ee[0], dy = e.cx[1] - e.ee[1], dz = e.cx[2] - e.ee[2];
+            if (tsqrt(dx*dx + dy*dy + dz*dz) < 0.03f) {
+                const float bx = e.bp[0] - e.lbp[0], by = e.bp[1] - e.lbp[1], bz = e.bp[2] - e.lbp[2];
+                reward += tsqrt(bx*bx + by*by + bz*bz)*20.0f;
+                set_random_block_position(e, 2, 0.22f, u);
+            }
+        }
+        physics_substeps(e, ctrl, p, false, P, cstale);
+        // stale poses -> persistent (read by the next step's reward) and -> obs; ref: env_base_01.py:118-127, 241-270
+#pragma unroll
+        for (int i = 0; i < 3; i++) { e.ee[i] = P.jaw_pos[i] + P.jaw_mat[3*i + 1]*(-0.1f); e.cx[i] = cstale[i]; }
+        e.wrist_z = P.wrist[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) obs[i] = e.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { obs[6 + i] = e.cx[i] - e.ee[i]; obs[9 + i] = e.cx[i]; obs[12 + i] = e.ee[i]; }
+    } else {
+        // ref: env03_v1.py:124-201 (Env03, Env05) / env04_v1.py:62-160 (Env04)
+        const float h = (float)so100g::TIMESTEP;
+        const float time = (float)e.nsub*h;
+        const float frac = tmin(time/12.0f, 1.0f);
+        float smin[3], smax[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { smin[i] = SPACE_START[0][i]; smax[i] = SPACE_START[1][i]; }
+        if (KIND != 4) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) {                                  // _update_block_space :59-68
+                const float e0 = KIND == 5 ? SPACE_END_05[0][i] : SPACE_END_03[0][i];
+                const float e1 = KIND == 5 ? SPACE_END_05[1][i] : SPACE_END_03[1][i];
+                smin[i] = SPACE_START[0][i] + frac*(e0 - SPACE_START[0][i]);
+                smax[i] = SPACE_START[1][i] + frac*(e1 - SPACE_START[1][i]);
+            }
+            const float speed = frac <= 0.05f ? 0.0f : (frac - 0.05f)*2.0f/(1.0f - 0.05f);   // :70-75
+            {                                                              // _update_block_target :77-93
+                const float tx = e.tgt[0] - e.cube.pos[0], ty = e.tgt[1] - e.cube.pos[1], tz = e.tgt[2] - e.cube.pos[2];
+                const float dist_t = tsqrt(tx*tx + ty*ty + tz*tz);
+                if (!(time - e.ttime < e.tdt && dist_t > 0.02f)) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) e.tgt[i] = smin[i] + (smax[i] - smin[i])*u[i];
+                    e.tdt = 1.2f + (5.1f - 1.2f)*u[3];
+                    e.ttime = time;
+                }
+            }
+            {                                                              // _update_block_position :95-122
+                const float tx = e.tgt[0] - e.cube.pos[0], ty = e.tgt[1] - e.cube.pos[1], tz = e.tgt[2] - e.cube.pos[2];
+                const float dist = tsqrt(tx*tx + ty*ty + tz*tz);
+                if (dist > 0.0f) {
+                    const float sd = tmin(speed*h, dist), inv = 1.0f/dist;
+                    e.cube.pos[0] += tx*inv*sd; e.cube.pos[1] += ty*inv*sd; e.cube.pos[2] += tz*inv*sd;
+                    e.cube.vel[0] = e.cube.vel[1] = e.cube.vel[2] = 0.0f;
+                    e.bits |= B_ANTIGRAV;                                  // qfrc_applied = -m g, kept until reset
+                }
+            }
+        }
+        float old[6], ncmd[6], ctrl[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) { old[i] = e.cmd[i]; ncmd[i] = e.cmd[i] + a[i]*JOINT_STEP_SCALE; ctrl[i] = ncmd[i]; }
+        physics_substeps(e, ctrl, p, true, P, cstale);
+        // ref: env05_v1.py:32-75 (Env03/04: the same reprojection stands in for render + YOLO, no noise)
+        float cxn = -1.0f, cyn = -1.0f; int pu, pv;
+        if (project(P.cam_pos, P.cam_mat, e.cube.pos, pu, pv)) {
+            cxn = (float)pu/1080.0f; cyn = (float)pv/1920.0f;
+            if (KIND == 5) { cxn += -0.05f + 0.1f*u[4]; cyn += -0.05f + 0.1f*u[5]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) obs[i] = old[i];
+        obs[6] = cxn; obs[7] = cyn;
+        if (cxn == -1.0f && cyn == -1.0f) {                                // :152-164
+            if (e.lost > 30) term = true;
+            e.lost++;
+            if (KIND == 4) { obs[6] = e.lc[0]; obs[7] = e.lc[1]; }
+        } else { e.lc[0] = cxn; e.lc[1] = cyn; e.bits |= B_HAVE_CENTER; e.lost = 0; }
+        reward = 0.5f;
+        if (e.bits & B_HAVE_CENTER) {
+            const float fx = 0.5f - e.lc[0], fy = 0.5f - e.lc[1];
+            const float dd = tsqrt(fx*fx + fy*fy);
+            if (KIND == 4) {                                               // env04_v1.py:108-131
+                reward += __builtin_expf(-10.0f*dd);
+                reward += -1.0f*dd;
+                if (dd < 0.1f && !(e.bits & B_BLOCK_UPDATED)) {
+                    e.bits |= B_BLOCK_UPDATED;
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { e.tgt[i] = smin[i] + (smax[i] - smin[i])*u[i]; e.cube.pos[i] = e.tgt[i]; }
+                    reward += 10.0f;
+                }
+            } else reward += -1.0f*dd;                                     // env03_v1.py:168-176
+        }
+        reward += joint_reward(old);
+        if (KIND == 4) {                                                   // env04_v1.py:137-148
+            const float wr = tclamp(joint_penalty(old[4], START_POSITION[4] - 0.2f, START_POSITION[4] + 0.2f), -0.2f, 0.0f);
+            reward += wr*0.5f;
+        } else {                                                           // env03_v1.py:182-189, env_base_01.py:165-178
+            float pen = 0.0f, av[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) av[i] = (ncmd[i] - old[i])/h;
+            if (e.bits & B_HAVE_ANGVEL) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) pen += tabs(av[i] - e.av[i])*0.0025f;
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) e.av[i] = av[i];
+            e.bits |= B_HAVE_ANGVEL;
+            reward += (-pen)*frac;
+        }
+        obs[6] = 5.0f*obs[6]; obs[7] = 5.0f*obs[7];                        // :195-196 (Q4)
+#pragma unroll
+        for (int i = 0; i < 6; i++) e.cmd[i] = ncmd[i];                    // :198
+    }
+    return reward;
+}
+
+// Env.step + gymnasium TimeLimit + SB3 DummyVecEnv auto-reset, for one env
+struct StepResult { float reward; bool done, trunc_only; float ep_return; int ep_length; };
+
+template <int KIND> SO100_HD StepResult env_step_vec(EnvState& e, const float a[6], const SimParams& p, uint32_t env_gid,
+                                                      const float* inject, const float* start_tab, float* obs, float* terminal_obs) {
+    float u[8];
+    draw8(p, env_gid, (uint32_t)e.rngc, 0, inject, u);
+    e.rngc++;
+    bool term;
+    StepResult r;
+    r.reward = env_step<KIND>(e, a, u, p, obs, term);
+    e.elapsed++;
+    const bool trunc = p.max_episode_steps > 0 && e.elapsed >= p.max_episode_steps;
+    e.epret += r.reward; e.eplen++;
+    r.done = term || trunc; r.trunc_only = trunc && !term;
+    r.ep_return = e.epret; r.ep_length = e.eplen;
+    if (r.done) {
+#pragma unroll
+        for (int i = 0; i < obs_dim<KIND>(); i++) terminal_obs[i] = obs[i];
+        draw8(p, env_gid, (uint32_t)e.rngc, 1, inject, u);
+        e.rngc++;
+        env_reset<KIND>(e, u, start_tab, obs);
+    }
+    return r;
+}
+
+}  // namespace so100

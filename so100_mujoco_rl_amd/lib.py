@@ -1,0 +1,179 @@
+"""ctypes binding of libso100sim.so (C ABI: include/so100_sim.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every tensor crosses the boundary as a raw
+device pointer (`tensor.data_ptr()`) plus the current HIP stream handle.  There is NO CPU fallback: if the
+shared object is missing or no HIP device is usable, loading / `So100Sim()` raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import torch  # imported BEFORE the .so so that both bind to the same libamdhip64 (see csrc/Makefile)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libso100sim.so")
+
+ENV01, ENV02, ENV03, ENV04, ENV05 = 1, 2, 3, 4, 5
+F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
+F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR
+NINJECT = 16
+
+
+class So100Error(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("env_kind", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
+                ("solver_iters", C.c_int32), ("contact_iters", C.c_int32), ("frame_skip", C.c_int32),
+                ("max_episode_steps", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class StepIO(C.Structure):
+    _fields_ = [("act_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("rew_dev", C.c_void_p), ("done_dev", C.c_void_p),
+                ("trunc_dev", C.c_void_p), ("terminal_obs_dev", C.c_void_p), ("ep_return_dev", C.c_void_p),
+                ("ep_length_dev", C.c_void_p), ("inject_dev", C.c_void_p)]
+
+
+EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_create",
+           "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
+           "so100_set_field", "so100_last_error"]
+
+
+def build(verbose=False):
+    """Compile libso100sim.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise So100Error("building libso100sim.so failed:\n" + out.stdout[-4000:] + out.stderr[-4000:])
+    if verbose:
+        print(out.stdout[-3000:])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the shared object (built in-tree; never falls back to anything else)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise So100Error(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        L.so100_last_error.restype = C.c_char_p
+        L.so100_state_field_index.argtypes = [C.c_char_p]
+        L.so100_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.so100_destroy.argtypes = [C.c_void_p]
+        L.so100_destroy.restype = None
+        L.so100_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so100_step.argtypes = [C.c_void_p, C.POINTER(StepIO), C.c_void_p]
+        L.so100_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so100_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.so100_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.so100_set_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        if L.so100_abi_version() != 1:
+            raise So100Error("libso100sim.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise So100Error(f"{what} failed ({rc}): {load().so100_last_error().decode()}")
+
+
+def _ptr(t, dtype, shape, device):
+    if t is None:
+        return None
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device != device:
+        raise So100Error(f"bad tensor: want {dtype} {tuple(shape)} contiguous on {device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t.data_ptr()
+
+
+class So100Sim:
+    """One batched simulator handle on one GPU (one per process per device)."""
+
+    def __init__(self, env_kind, num_envs, device=None, flags=F_REFERENCE, solver_iters=3, contact_iters=4,
+                 frame_skip=16, max_episode_steps=None, seed=0, env_id_offset=0):
+        self.L = load()
+        if not torch.cuda.is_available():
+            raise So100Error("no HIP device visible to PyTorch: so100 has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if max_episode_steps is None:
+            max_episode_steps = 4000 if env_kind == ENV01 else 6000       # ref: so100_mujoco_rl/__init__.py:5-38
+        self.cfg = Config(env_kind, num_envs, self.device.index, flags, solver_iters, contact_iters, frame_skip,
+                          max_episode_steps, seed, env_id_offset, 0)
+        h = C.c_void_p()
+        _check(self.L.so100_create(C.byref(self.cfg), C.byref(h)), "so100_create")
+        self.h = h
+        self.n = num_envs
+        self.kind = env_kind
+        self.obs_dim = self.L.so100_obs_dim(env_kind)
+        kw = dict(device=self.device)
+        self.obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
+        self.rew = torch.zeros(num_envs, dtype=torch.float32, **kw)
+        self.done = torch.zeros(num_envs, dtype=torch.uint8, **kw)
+        self.trunc = torch.zeros(num_envs, dtype=torch.uint8, **kw)
+        self.terminal_obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
+        self.ep_return = torch.zeros(num_envs, dtype=torch.float32, **kw)
+        self.ep_length = torch.zeros(num_envs, dtype=torch.int32, **kw)
+        self._io = StepIO()
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.so100_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self, mask=None, inject=None):
+        """Reset all envs (mask None) or those with mask != 0.  Returns the (persistent) obs tensor."""
+        m = _ptr(mask, torch.uint8, (self.n,), self.device)
+        i = _ptr(inject, torch.float32, (self.n, NINJECT), self.device)
+        _check(self.L.so100_reset(self.h, m, i, self.obs.data_ptr(), self._stream()), "so100_reset")
+        return self.obs
+
+    def step(self, actions, inject=None):
+        """actions: float32 [N,6] on the device.  Returns views of the handle's output tensors."""
+        io = self._io
+        io.act_dev = _ptr(actions, torch.float32, (self.n, 6), self.device)
+        io.obs_dev = self.obs.data_ptr(); io.rew_dev = self.rew.data_ptr()
+        io.done_dev = self.done.data_ptr(); io.trunc_dev = self.trunc.data_ptr()
+        io.terminal_obs_dev = self.terminal_obs.data_ptr()
+        io.ep_return_dev = self.ep_return.data_ptr(); io.ep_length_dev = self.ep_length.data_ptr()
+        io.inject_dev = _ptr(inject, torch.float32, (self.n, NINJECT), self.device)
+        _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
+        return self.obs, self.rew, self.done, self.trunc
+
+    def get_state(self):
+        qpos = torch.empty(13, self.n, dtype=torch.float32, device=self.device)
+        qvel = torch.empty(12, self.n, dtype=torch.float32, device=self.device)
+        _check(self.L.so100_get_state(self.h, qpos.data_ptr(), qvel.data_ptr(), self._stream()), "so100_get_state")
+        return qpos, qvel
+
+    def set_state(self, qpos, qvel):
+        _check(self.L.so100_set_state(self.h, _ptr(qpos, torch.float32, (13, self.n), self.device),
+                                      _ptr(qvel, torch.float32, (12, self.n), self.device), self._stream()), "so100_set_state")
+
+    def field_index(self, name):
+        i = self.L.so100_state_field_index(name.encode())
+        if i < 0:
+            raise So100Error(f"unknown state field {name!r}")
+        return i
+
+    def get_field(self, name, dtype=torch.float32):
+        out = torch.empty(self.n, dtype=dtype, device=self.device)
+        _check(self.L.so100_get_field(self.h, self.field_index(name), out.data_ptr(), self._stream()), "so100_get_field")
+        return out
+
+    def set_field(self, name, value):
+        assert value.element_size() == 4
+        _check(self.L.so100_set_field(self.h, self.field_index(name), _ptr(value, value.dtype, (self.n,), self.device),
+                                      self._stream()), "so100_set_field")

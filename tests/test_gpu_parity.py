@@ -1,0 +1,268 @@
+"""GPU parity: the HIP path (through the C ABI) vs the fp64 CPU oracle on identical seeded inputs, vs the golden
+trajectories recorded from the reference's Python, and size-independent properties at BASELINE.json sizes.
+
+Tolerances (fp32 device arithmetic vs fp64 oracle), stated per check:
+  * joint angles / cube position after up to 60 env steps (960 substeps): 2e-5 abs (north star: 1e-5 rel of
+    angles of magnitude ~1-3 rad); velocities 5e-4 abs
+  * observations 2e-5 abs, rewards 1e-4 abs
+  * Env05 pixel centre: exact, except when the fp64 sub-pixel coordinate is within 2e-3 px of an integer
+    boundary (then +-1 px = 9.3e-4 / 5.2e-4 in normalised units) -- expressed as a 6e-3 tolerance on 5*cx.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import so100_oracle as O                      # noqa: E402  (the checker)
+
+
+def _sim(*a, **k):
+    from so100_mujoco_rl_amd.lib import So100Sim
+    return So100Sim(*a, **k)
+
+
+REF = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
+ARM = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_CUBE_PINNED
+FREE = O.F_CUBE_PINNED
+
+
+def _run_pair(kind, flags, n, steps, seed, action_scale=1.0, solver_iters=4, contact_iters=6, max_steps=0, inject=True):
+    """Step n envs on the GPU and in the oracle with identical actions / uniforms; yield per-step results."""
+    rs = np.random.RandomState(seed)
+    sim = _sim(kind, n, flags=flags, solver_iters=solver_iters, contact_iters=contact_iters, max_episode_steps=max_steps, seed=seed)
+    orc = [O.OracleEnv(kind, flags=flags, iters=0, seed=seed, env_id=i) for i in range(n)]
+    for e in orc:
+        e.e.max_episode_steps = max_steps
+    inj = rs.random_sample((n, 16)).astype(np.float32)
+    obs_g = sim.reset(inject=torch.from_numpy(inj).cuda() if inject else None).cpu().numpy().copy()
+    obs_o = np.stack([e.reset(inject=inj[i] if inject else None) for i, e in enumerate(orc)])
+    yield -1, sim, orc, obs_g, obs_o, None, None, None, None
+    for t in range(steps):
+        a = np.clip(rs.uniform(-1, 1, (n, 6)) * action_scale, -1, 1).astype(np.float32)
+        inj = rs.random_sample((n, 16)).astype(np.float32)
+        og, rg, dg, tg = sim.step(torch.from_numpy(a).cuda(), inject=torch.from_numpy(inj).cuda() if inject else None)
+        res = [e.step(a[i], inject=inj[i] if inject else None, autoreset=True) for i, e in enumerate(orc)]
+        oo = np.stack([r[0] for r in res]); ro = np.array([r[1] for r in res])
+        do = np.array([r[2] or r[3] for r in res]); to = np.array([r[3] and not r[2] for r in res])
+        yield t, sim, orc, og.cpu().numpy().copy(), oo, (rg.cpu().numpy().copy(), ro), (dg.cpu().numpy().copy(), do), (tg.cpu().numpy().copy(), to), res
+
+
+def _state_err(sim, orc):
+    qpos, qvel = sim.get_state()
+    qpos = qpos.cpu().numpy().T; qvel = qvel.cpu().numpy().T
+    qo = np.stack([O.arr(e.d.qpos).copy() for e in orc]); vo = np.stack([O.arr(e.d.qvel).copy() for e in orc])
+    return np.abs(qpos - qo).max(), np.abs(qvel - vo).max()
+
+
+@pytest.mark.parametrize("flags,name", [(FREE, "constraint-free"), (ARM, "friction+limits"), (REF, "reference")])
+def test_env01_vs_oracle(flags, name):
+    n, steps = (48, 40) if flags == REF else (96, 60)
+    worst_o = worst_r = 0.0
+    for t, sim, orc, og, oo, rew, done, trunc, _ in _run_pair(1, flags, n, steps, seed=7):
+        worst_o = max(worst_o, np.abs(og - oo).max())
+        if rew is not None:
+            worst_r = max(worst_r, np.abs(rew[0] - rew[1]).max())
+            assert not done[0].any() and not done[1].any()
+    eq, ev = _state_err(sim, orc)
+    print(f"[{name}] obs {worst_o:.2e} reward {worst_r:.2e} qpos {eq:.2e} qvel {ev:.2e}")
+    assert worst_o < 2e-5 and worst_r < 1e-4
+    assert eq < 2e-5 and ev < 5e-4
+
+
+def test_env02_vs_oracle_with_reach_branch():
+    n, steps = 64, 30
+    hits = 0
+    gen = _run_pair(2, ARM, n, steps, seed=11)
+    for t, sim, orc, og, oo, rew, done, trunc, _ in gen:
+        np.testing.assert_allclose(og, oo, rtol=0, atol=2e-5)
+        if rew is not None:
+            np.testing.assert_allclose(rew[0], rew[1], rtol=0, atol=1e-4)
+            hits += int((rew[1] > 1.0).sum())
+        if t in (3, 9, 15):
+            # force the reach branch (< 3 cm): teleport every 4th cube onto the stale end effector, on both sides
+            ee = torch.stack([sim.get_field(f"ee_{c}") for c in "xyz"])
+            for c, k in zip("xyz", range(3)):
+                cx = sim.get_field(f"cx_{c}"); cx[::4] = ee[k][::4]; sim.set_field(f"cx_{c}", cx)
+            for i in range(0, n, 4):
+                d = orc[i].d
+                e3 = np.zeros(3); O.lib().so100o_end_effector(d.xpos[6], d.xmat[6], e3.ctypes.data_as(O.C.c_void_p))
+                O.arr(d.xpos)[8] = e3
+    assert hits >= 3 * (n // 4) - 2           # the bonus fired (20 * distance between samples)
+    eq, ev = _state_err(sim, orc)
+    assert eq < 2e-5 and ev < 5e-4
+
+
+@pytest.mark.parametrize("kind", [5, 3, 4])
+def test_lookat_envs_vs_oracle(kind):
+    n, steps = 64, 60
+    flags = REF if kind == 5 else ARM | 0
+    if kind != 5:
+        flags = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
+    n_px = n_px_bad = 0
+    for t, sim, orc, og, oo, rew, done, trunc, _ in _run_pair(kind, flags, n, steps, seed=20 + kind, action_scale=0.6):
+        np.testing.assert_allclose(og[:, :6], oo[:, :6], rtol=0, atol=1e-6)
+        d = np.abs(og[:, 6:] - oo[:, 6:])
+        n_px += d.size; n_px_bad += int((d > 1e-4).sum())
+        assert d.max() < 6e-3, (t, d.max())
+        if rew is not None:
+            np.testing.assert_allclose(rew[0], rew[1], rtol=0, atol=2e-3)
+            np.testing.assert_array_equal(done[0].astype(bool), done[1])
+    assert n_px_bad <= 0.01 * n_px               # off-by-one pixels are rare
+    eq, ev = _state_err(sim, orc)
+    assert eq < 3e-5 and ev < 5e-4
+
+
+def test_env05_termination_and_autoreset():
+    """Rotate the base away until the cube is lost for > 30 steps: terminated, terminal obs, auto-reset."""
+    n = 64
+    sim = _sim(5, n, flags=REF, contact_iters=6, max_episode_steps=0, seed=3)
+    orc = [O.OracleEnv(5, flags=REF, iters=0, seed=3, env_id=i) for i in range(n)]
+    for e in orc:
+        e.e.max_episode_steps = 0
+    rs = np.random.RandomState(5)
+    sim.reset(inject=torch.zeros(n, 16).cuda())
+    [e.reset(inject=np.zeros(16, np.float32)) for e in orc]
+    n_done = 0
+    for t in range(60):
+        a = np.zeros((n, 6), np.float32); a[:, 0] = 1.0 if t < 28 else 0.0
+        a[n // 2:, 0] = 0.0                                   # half of the envs keep looking at the cube
+        inj = rs.random_sample((n, 16)).astype(np.float32)
+        og, rg, dg, tg = sim.step(torch.from_numpy(a).cuda(), inject=torch.from_numpy(inj).cuda())
+        res = [e.step(a[i], inject=inj[i], autoreset=True) for i, e in enumerate(orc)]
+        do = np.array([r[2] for r in res])
+        np.testing.assert_array_equal(dg.cpu().numpy().astype(bool), do)
+        assert not tg.any()
+        if do.any():
+            n_done += int(do.sum())
+            tob = sim.terminal_obs.cpu().numpy()
+            for i in np.nonzero(do)[0]:
+                np.testing.assert_allclose(tob[i], res[i][4], rtol=0, atol=6e-3)
+                np.testing.assert_allclose(og.cpu().numpy()[i], res[i][0], rtol=0, atol=1e-6)   # reset obs
+                assert sim.ep_length.cpu().numpy()[i] == t + 1
+    assert n_done == n // 2
+
+
+def test_timelimit_truncation_and_episode_stats():
+    n = 128
+    sim = _sim(1, n, flags=FREE, max_episode_steps=7, seed=1)
+    sim.reset()
+    el = torch.arange(n, dtype=torch.int32).cuda() % 7
+    sim.set_field("elapsed_steps", el)
+    ret = np.zeros(n); length = np.zeros(n, int)
+    for t in range(10):
+        a = torch.zeros(n, 6).cuda()
+        ob, r, d, tr = sim.step(a)
+        elapsed = (el.cpu().numpy() + t + 1)
+        want = (elapsed % 7) == 0
+        np.testing.assert_array_equal(d.cpu().numpy().astype(bool), want)
+        np.testing.assert_array_equal(tr.cpu().numpy().astype(bool), want)      # truncated, never terminated
+        ret += r.cpu().numpy(); length += 1
+        idx = np.nonzero(want)[0]
+        np.testing.assert_allclose(sim.ep_return.cpu().numpy()[idx], ret[idx], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(sim.ep_length.cpu().numpy()[idx], length[idx])
+        ret[idx] = 0; length[idx] = 0
+        # reset observation (all poses zero) replaces the terminal one
+        assert np.all(ob.cpu().numpy()[idx, 6:] == 0)
+        assert np.all(sim.terminal_obs.cpu().numpy()[idx, 12:] != 0)
+
+
+def test_device_rng_matches_oracle_philox():
+    """No injection: the device Philox stream equals the oracle's, so resets agree (up to fp32 sin/cos)."""
+    n = 256
+    for kind in (1, 2):
+        sim = _sim(kind, n, flags=FREE, seed=0xDEADBEEF12345, env_id_offset=1000)
+        og = sim.reset().cpu().numpy()
+        for i in range(0, n, 17):
+            e = O.OracleEnv(kind, flags=FREE, seed=0xDEADBEEF12345, env_id=1000 + i)
+            np.testing.assert_allclose(og[i], e.reset(), rtol=0, atol=1e-6)
+        qpos, _ = sim.get_state()
+        e = O.OracleEnv(kind, flags=FREE, seed=0xDEADBEEF12345, env_id=1000 + 5); e.reset()
+        np.testing.assert_allclose(qpos[:, 5].cpu().numpy(), O.arr(e.d.qpos), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_golden_trajectories_on_gpu(golden_dir, idx):
+    """The trajectories recorded from the reference's own Python (over oracle physics) replayed on the HIP path."""
+    tr = json.load(open(os.path.join(golden_dir, "trajectories.json")))[idx]
+    n = 64                                              # 64 identical lanes; lane 0 and lane 63 are checked
+    sim = _sim(tr["kind"], n, flags=tr["flags"], solver_iters=4, contact_iters=6, max_episode_steps=0)
+    rep = lambda v: torch.tensor(np.tile(np.array(v, np.float32), (n, 1))).cuda()
+    ob = sim.reset(inject=rep(tr["reset_inject"])).cpu().numpy()
+    np.testing.assert_allclose(ob[0], np.array(tr["reset_obs"], np.float32), rtol=0, atol=1e-6)
+    lookat = tr["kind"] >= 3
+    for k, s in enumerate(tr["steps"]):
+        if s.get("pre_teleport"):
+            for c, j in zip("xyz", range(3)):
+                sim.set_field(f"cube_{c}", torch.full((n,), s["pre_teleport"]["cube_qpos"][j]).cuda())
+                sim.set_field(f"cx_{c}", torch.full((n,), s["pre_teleport"]["cube_xpos"][j]).cuda())
+        ob, r, d, trc = sim.step(rep(s["action"]), inject=rep(s["inject"]))
+        ob = ob.cpu().numpy(); want = np.array(s["obs"], np.float32)
+        got = sim.terminal_obs.cpu().numpy() if s["terminated"] else ob
+        for lane in (0, n - 1):
+            if lookat:
+                np.testing.assert_allclose(got[lane][:6], want[:6], rtol=0, atol=1e-6, err_msg=f"step {k}")
+                np.testing.assert_allclose(got[lane][6:], want[6:], rtol=0, atol=6e-3, err_msg=f"step {k}")
+            else:
+                np.testing.assert_allclose(got[lane], want, rtol=0, atol=2e-5, err_msg=f"step {k}")
+            assert abs(r.cpu().numpy()[lane] - s["reward"]) < (2e-3 if lookat else 1e-4), f"step {k}"
+            assert bool(d.cpu().numpy()[lane]) == s["terminated"]
+        if s["terminated"]:
+            np.testing.assert_allclose(ob[0], np.array(s["reset_obs"], np.float32), rtol=0, atol=1e-6)
+        elif s["reset_after"]:
+            ob2 = sim.reset(inject=rep(s["inject"])).cpu().numpy()
+            np.testing.assert_allclose(ob2[0], np.array(s["reset_obs"], np.float32), rtol=0, atol=1e-6)
+    qpos, qvel = sim.get_state()
+    if not tr["steps"][-1]["reset_after"]:
+        np.testing.assert_allclose(qpos[:, 0].cpu().numpy(), tr["steps"][-1]["qpos"], rtol=0, atol=3e-5)
+
+
+def test_state_roundtrip_and_errors():
+    from so100_mujoco_rl_amd import lib
+    sim = _sim(1, 100, flags=FREE)
+    sim.reset()
+    qpos, qvel = sim.get_state()
+    qpos2 = qpos + 0.01; qvel2 = qvel - 0.5
+    sim.set_state(qpos2.contiguous(), qvel2.contiguous())
+    a, b = sim.get_state()
+    assert torch.equal(a, qpos2) and torch.equal(b, qvel2)
+    with pytest.raises(lib.So100Error):
+        sim.step(torch.zeros(99, 6).cuda())               # wrong batch size
+    with pytest.raises(lib.So100Error):
+        lib.So100Sim(9, 10)                               # bad env kind
+    with pytest.raises(lib.So100Error):
+        lib.So100Sim(1, 10, flags=lib.F_FLOOR | lib.F_CUBE_PINNED)
+
+
+# ---- size-independent properties at BASELINE.json's full sizes ---------------------------------------------------
+@pytest.mark.parametrize("kind,n", [(1, 4096), (2, 16384), (5, 8192)])
+def test_full_size_properties(kind, n):
+    """determinism, shard invariance (env_id_offset), joint limits, finiteness, obs-space bounds"""
+    flags = FREE if kind == 1 else REF
+    g = torch.Generator(device="cuda"); g.manual_seed(0)
+    acts = [torch.rand(n, 6, device="cuda", generator=g) * 2 - 1 for _ in range(12)]
+
+    def rollout(n_envs, offset, acts_slice):
+        sim = _sim(kind, n_envs, flags=flags, seed=99, env_id_offset=offset)
+        outs = [sim.reset().clone()]
+        for a in acts:
+            ob, r, d, tr = sim.step(a[acts_slice].contiguous())
+            outs.append(torch.cat([ob, r[:, None], d[:, None].float()], 1).clone())
+        q, v = sim.get_state()
+        return torch.cat(outs, 1), q, v
+    full, q, v = rollout(n, 0, slice(0, n))
+    again, _, _ = rollout(n, 0, slice(0, n))
+    assert torch.equal(full, again)                                         # bitwise deterministic
+    half = n // 2
+    lo, _, _ = rollout(half, 0, slice(0, half)); hi, _, _ = rollout(half, half, slice(half, n))
+    assert torch.equal(torch.cat([lo, hi], 0), full)                        # sharding leaves every env unchanged
+    assert torch.isfinite(full).all() and torch.isfinite(q).all() and torch.isfinite(v).all()
+    from so100_mujoco_rl_amd.constants import JOINT_RANGES
+    for i, (a, b) in enumerate(JOINT_RANGES):
+        if flags & O.F_LIMITS:
+            assert q[i].min() > a - 0.05 and q[i].max() < b + 0.05          # soft limits hold
+    nq = torch.linalg.vector_norm(q[9:13], dim=0)
+    assert (nq - 1).abs().max() < 1e-5                                      # cube quaternion stays normalised
