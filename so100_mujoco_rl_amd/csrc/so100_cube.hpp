@@ -36,7 +36,7 @@ template <typename T> SO100_HD void quat_to_mat(const T q[4], T m[9]) {
 template <typename T> SO100_HD void quat_normalize(T q[4]) {
     const T n = tsqrt(q[0]*q[0] + q[1]*q[1] + q[2]*q[2] + q[3]*q[3]);
     if (n < T(1e-15)) { q[0] = T(1); q[1] = q[2] = q[3] = T(0); return; }
-    const T r = T(1)/n;
+    const T r = trcp(n);
     q[0] *= r; q[1] *= r; q[2] *= r; q[3] *= r;
 }
 
@@ -124,7 +124,7 @@ SO100_HD void cube_row_setup(CubeRows<T>& r, const T a0[3], const T vl[3], const
     const T jv = d0*vl[0] + d1*vl[1] + d2*vl[2] + dot(ja, va);
     const T ja0 = d0*a0[0] + d1*a0[1] + d2*a0[2];                 // angular a0 is zero (isotropic, no torque)
     r.b[S][E] = ja0 + T(so100g::SOLREF_B)*jv + Kimpdist;
-    r.arinv[S][E] = T(1)/r.R[S];
+    r.arinv[S][E] = trcp(r.R[S]);
 }
 
 template <typename T>
@@ -170,7 +170,7 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
             r.rl[s][0] = v[0] - Rm[6]*hd; r.rl[s][1] = v[1] - Rm[7]*hd; r.rl[s][2] = v[2] - Rm[8]*hd;
             const T imp = impedance(tabs(dist[s]));
             // R = 2 mu^2 * (1-imp)/imp * diagApprox, diagApprox = (1 + mu^2)/m, mu = 1
-            r.R[s] = T(4.0/so100g::CUBE_MASS)*(T(1) - imp)/imp;
+            r.R[s] = T(4.0/so100g::CUBE_MASS)*(T(1) - imp)*trcp(imp);
             dist[s] = T(so100g::SOLREF_K)*imp*dist[s];            // K imp dist
         }
         // edge directions in the body frame: dl = R^T dir
@@ -196,6 +196,16 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
                 for (int i = 0; i < 6; i++) dx[i] = -g[i];
                 ldl6(Hm, Dinv);
                 ldl6_solve(Hm, Dinv, dx);
+                // converged when the Newton step no longer changes the acceleration (fp32: ~1e-6 g): at rest the
+                // warm start is already the optimum, so a resting cube costs one gradient/Hessian evaluation
+                const T tol = sizeof(T) == 4 ? T(2e-5) : T(1e-11);
+                const T dmax = tmax(tmax(tabs(dx[0]), tabs(dx[1])), tabs(dx[2]));
+                const T amax = tmax(tmax(tabs(dx[3]), tabs(dx[4])), tabs(dx[5]))*T(so100g::CUBE_HALF);
+                if (tmax(dmax, amax) < tol) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) x[i] += dx[i];
+                    break;
+                }
                 // exact line search: phi'(alpha) is increasing and piecewise linear; root by safeguarded Newton
                 T j0[4][4], jd[4][4];
 #define SO100_LIN(S) cube_row_lin<S, 0>(r, x, dx, j0, jd); cube_row_lin<S, 1>(r, x, dx, j0, jd); \
@@ -209,10 +219,10 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
                 for (int ls = 0; ls < 10; ls++) {
                     cube_phi(r, j0, jd, q1, q2, alpha, d1, d2);
                     if (d1 < T(0)) lo = alpha; else hi = alpha;
-                    T an = d2 > T(0) ? alpha - d1/d2 : alpha;
+                    T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
                     const bool inside = an > lo && (hi < T(0) || an < hi);
                     if (!inside) an = hi < T(0) ? T(2)*alpha : T(0.5)*(lo + hi);
-                    if (an == alpha) break;
+                    if (tabs(an - alpha) <= T(1e-6)*tabs(alpha)) { alpha = an; break; }
                     alpha = an;
                 }
 #pragma unroll
@@ -234,7 +244,7 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
         T w[3] = { c.vel[3], c.vel[4], c.vel[5] };
         const T nrm = tsqrt(dot(w, w));
         if (nrm < T(1e-15)) { w[0] = T(1); w[1] = T(0); w[2] = T(0); }
-        else { const T rn = T(1)/nrm; w[0] *= rn; w[1] *= rn; w[2] *= rn; }
+        else { const T rn = trcp(nrm); w[0] *= rn; w[1] *= rn; w[2] *= rn; }
         T sn, cs; tsincos<T>(T(0.5)*h*nrm, sn, cs);
         quat_normalize(c.quat);
         const T a = c.quat[0], b = c.quat[1], cc = c.quat[2], d = c.quat[3];

@@ -34,6 +34,16 @@ template <typename T> SO100_HD T tabs(T a) { return a < T(0) ? -a : a; }
 
 SO100_HD float  tsqrt(float x)  { return __builtin_sqrtf(x); }
 SO100_HD double tsqrt(double x) { return __builtin_sqrt(x); }
+// reciprocal: on the device one v_rcp_f32 (1 ulp) plus a Newton step instead of the ~10-instruction IEEE division
+SO100_HD float trcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+#else
+    return 1.0f/x;
+#endif
+}
+SO100_HD double trcp(double x) { return 1.0/x; }
 SO100_HD float  tfloor(float x)  { return __builtin_floorf(x); }
 SO100_HD double tfloor(double x) { return __builtin_floor(x); }
 
@@ -306,7 +316,7 @@ template <typename T> SO100_HD void ldl6(T M[21], T Dinv[6]) {     // M <- L (un
 #pragma unroll
         for (int k = 0; k < j; k++) d -= M[SO100_TRI(j, k)]*M[SO100_TRI(j, k)]*M[SO100_TRI(k, k)];
         M[SO100_TRI(j, j)] = d;
-        Dinv[j] = T(1)/d;
+        Dinv[j] = trcp(d);
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
             T t = M[SO100_TRI(i, j)];
@@ -417,7 +427,7 @@ SO100_HD void arm_substep(T q[6], T v[6], const T ctrl[6], T ff[6], T fl[6], uns
             const T dist = lo ? dlo : dhi;
             sg[i] = lo ? T(1) : T(-1);
             const T imp = impedance(tabs(dist));
-            Rl[i] = (T(1) - imp)/imp * T(so100g::DOF_INVWEIGHT0[i]);
+            Rl[i] = (T(1) - imp)*trcp(imp) * T(so100g::DOF_INVWEIGHT0[i]);
             bl[i] = sg[i]*a0[i] + Bd*sg[i]*v[i] + Kd*imp*dist;
             if (!act) { fl[i] = T(0); sg[i] = T(0); }          // inactive row: force pinned at 0
             else fl[i] = tmax(fl[i], T(0));
@@ -428,8 +438,13 @@ SO100_HD void arm_substep(T q[6], T v[6], const T ctrl[6], T ff[6], T fl[6], uns
         // |f| <= fmax, l >= 0  is solved exactly by enumerating its active sets; the coupling between joints
         // (armature-dominated M => nearly diagonal Minv) then converges in a few sweeps.
         T tq[6];                                              // joint-space constraint torque J^T f
+        T rAf[6], rAl[6], rdet[6];                            // sweep-invariant reciprocals of the 2x2 blocks
 #pragma unroll
-        for (int i = 0; i < 6; i++) tq[i] = ff[i] + sg[i]*fl[i];
+        for (int i = 0; i < 6; i++) {
+            tq[i] = ff[i] + sg[i]*fl[i];
+            const T a = sym6(Minv, i, i), Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a;
+            rAf[i] = trcp(Af); rAl[i] = trcp(Al); rdet[i] = trcp(Af*Al - cx*cx);
+        }
         for (int it = 0; it < iters; it++) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
@@ -441,14 +456,13 @@ SO100_HD void arm_substep(T q[6], T v[6], const T ctrl[6], T ff[6], T fl[6], uns
                 const T cf = bf[i] + wo, cl = bl[i] + sg[i]*wo;
                 const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a, F = fmax_[i];
                 // (1) limit row inactive
-                const T f1 = tclamp(-cf/Af, -F, F);
+                const T f1 = tclamp(-cf*rAf[i], -F, F);
                 const bool ok1 = (sg[i] == T(0)) || (cl + cx*f1 >= T(0));
                 // (2) both interior
-                const T det = Af*Al - cx*cx;
-                const T f2 = (cx*cl - cf*Al)/det, l2 = (cx*cf - Af*cl)/det;
+                const T f2 = (cx*cl - cf*Al)*rdet[i], l2 = (cx*cf - Af*cl)*rdet[i];
                 const bool ok2 = tabs(f2) <= F && l2 >= T(0);
                 // (3) friction saturated, limit active
-                const T lp = tmax(-(cl + cx*F)/Al, T(0)), lm = tmax(-(cl - cx*F)/Al, T(0));
+                const T lp = tmax(-(cl + cx*F)*rAl[i], T(0)), lm = tmax(-(cl - cx*F)*rAl[i], T(0));
                 const bool okp = cf + Af*F + cx*lp <= T(0);
                 const T f3 = okp ? F : -F, l3 = okp ? lp : lm;
                 const T fn = ok1 ? f1 : (ok2 ? f2 : f3);

@@ -54,10 +54,13 @@ struct StepPtrs {
 
 // K1: one fused env step (reward -> ctrl -> 16 x {FK, CRB, RNE, servo, rows, block-PGS / Newton, Euler} -> obs
 //     -> TimeLimit -> auto-reset), SURVEY.md section 8a rows a1-a10.
-template <int KIND>
+// FL >= 0: the physics flags are a compile-time constant (dead constraint families are not even compiled in:
+// fewer live registers, smaller loop body); FL < 0: flags read from the handle at run time.
+template <int KIND, int FL>
 __global__ void __launch_bounds__(WG) so100_step_fused(SimParams p, StepPtrs io) {
     const int env = blockIdx.x*WG + threadIdx.x;
     if (env >= p.n) return;
+    if (FL >= 0) p.flags = (unsigned)FL;
     EnvState e;
     load_env<KIND>(io.state, p.n, env, e);
     float a[6];
@@ -148,7 +151,17 @@ struct DeviceGuard {
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
 template <int KIND> int launch_step(so100_sim* s, const StepPtrs& io, hipStream_t st) {
-    hipLaunchKernelGGL(so100_step_fused<KIND>, grid_for(s->prm.n), dim3(WG), 0, st, s->prm, io);
+    const dim3 g = grid_for(s->prm.n), b(WG);
+    switch (s->prm.flags) {
+    case SO100_F_CUBE_PINNED:
+        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_CUBE_PINNED>), g, b, 0, st, s->prm, io); break;
+    case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED:
+        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED>), g, b, 0, st, s->prm, io); break;
+    case SO100_F_REFERENCE:
+        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_REFERENCE>), g, b, 0, st, s->prm, io); break;
+    default:
+        hipLaunchKernelGGL((so100_step_fused<KIND, -1>), g, b, 0, st, s->prm, io); break;
+    }
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }

@@ -311,7 +311,7 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
                 const float tx = e.tgt[0] - e.cube.pos[0], ty = e.tgt[1] - e.cube.pos[1], tz = e.tgt[2] - e.cube.pos[2];
                 const float dist = tsqrt(tx*tx + ty*ty + tz*tz);
                 if (dist > 0.0f) {
-                    const float sd = tmin(speed*h, dist), inv = 1.0f/dist;
+                    const float sd = tmin(speed*h, dist), inv = trcp(dist);
                     e.cube.pos[0] += tx*inv*sd; e.cube.pos[1] += ty*inv*sd; e.cube.pos[2] += tz*inv*sd;
                     e.cube.vel[0] = e.cube.vel[1] = e.cube.vel[2] = 0.0f;
                     e.bits |= B_ANTIGRAV;                                  // qfrc_applied = -m g, kept until reset

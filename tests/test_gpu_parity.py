@@ -109,7 +109,8 @@ def test_lookat_envs_vs_oracle(kind):
         n_px += d.size; n_px_bad += int((d > 1e-4).sum())
         assert d.max() < 6e-3, (t, d.max())
         if rew is not None:
-            np.testing.assert_allclose(rew[0], rew[1], rtol=0, atol=2e-3)
+            # one pixel (9.3e-4 of the frame) moves exp(-10 d) by up to ~1e-2 in Env04's reward
+            np.testing.assert_allclose(rew[0], rew[1], rtol=0, atol=1.2e-2 if kind == 4 else 2e-3)
             np.testing.assert_array_equal(done[0].astype(bool), done[1])
     assert n_px_bad <= 0.01 * n_px               # off-by-one pixels are rare
     eq, ev = _state_err(sim, orc)
