@@ -1,0 +1,63 @@
+"""Gymnasium single-env view (N = 1) of the batched simulator and the `register()` ids of the reference.
+
+ref: /root/reference/src/so100_mujoco_rl/__init__.py:5-38 registers Env01-v1 .. Env05-v1 (and Env06, out of scope) with
+max_episode_steps 4000/6000 and reward_threshold 6000/8000.  `register_envs()` does the same for this package's entry
+point when gymnasium is importable (it is not in the build image; the class works without it).
+Step/reset signatures follow Gymnasium: reset(seed, options) -> (obs, info); step(a) -> (obs, reward, terminated,
+truncated, info).  TimeLimit is applied by the simulator itself (max_episode_steps), so no wrapper is needed.
+"""
+import numpy as np
+import torch
+
+from . import constants as K
+from .lib import So100Sim, F_REFERENCE
+from .vec_env import make_spaces
+
+
+class So100Env:
+    metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
+
+    def __init__(self, env_kind=1, device=None, flags=F_REFERENCE, seed=0, render_mode=None, **kwargs):
+        self.kind = env_kind
+        self.observation_space, self.action_space = make_spaces(env_kind)
+        self._mk = lambda s: So100Sim(env_kind, 1, device=device, flags=flags, seed=s, max_episode_steps=K.MAX_EPISODE_STEPS[env_kind])
+        self.sim = self._mk(seed)
+        self.render_mode = render_mode
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:                            # unlike the reference (global np.random) seeding works
+            self.sim.close(); self.sim = self._mk(int(seed))
+        return self.sim.reset().cpu().numpy()[0].copy(), {}
+
+    def step(self, action):
+        a = torch.as_tensor(np.asarray(action, np.float32).reshape(1, 6)).to(self.sim.device)
+        # a single env never auto-resets in Gymnasium: run the step, report, and let the caller reset
+        obs, rew, done, trunc = self.sim.step(a)
+        d = bool(done.item()); tr = bool(trunc.item())
+        ob = (self.sim.terminal_obs if d else obs).cpu().numpy()[0].copy()
+        return ob, float(rew.item()), d and not tr, tr, {}
+
+    def close(self):
+        self.sim.close()
+
+    def render(self):
+        return None
+
+
+def _entry(kind):
+    def make(**kw):
+        return So100Env(kind, **kw)
+    return make
+
+
+def register_envs():
+    """gymnasium.register the reference's ids; returns the list of ids registered ([] if gymnasium is absent)."""
+    try:
+        from gymnasium.envs.registration import register
+    except Exception:
+        return []
+    ids = []
+    for kind, env_id in K.ENV_IDS.items():
+        register(id=env_id, entry_point=_entry(kind), max_episode_steps=None, reward_threshold=K.REWARD_THRESHOLD[kind])
+        ids.append(env_id)
+    return ids

@@ -51,3 +51,36 @@ void hc_cube_d(double* p, double* q, double* v, double* w, const double* a, unsi
 void hc_cube_f(double* p, double* q, double* v, double* w, const double* a, unsigned fg, int it, int n) { cube<float>(p, q, v, w, a, fg, it, n); }
 void hc_sincos_f(float x, float* s, float* c) { tsincos<float>(x, *s, *c); }
 }
+
+// ---- the full task layer (so100_task.hpp) on the host, fp32, one env ------------------------------------------------
+#include "../../so100_mujoco_rl_amd/csrc/so100_task.hpp"
+namespace { 
+#include "../../so100_mujoco_rl_amd/csrc/so100_start_positions.inc"
+float g_tab[36*6]; bool g_tab_ok = false;
+const float* tab() { if (!g_tab_ok) { for (int i = 0; i < 36; i++) for (int j = 0; j < 6; j++) g_tab[6*i+j] = (float)SO100_VALID_START_POSITIONS[i][j]; g_tab_ok = true; } return g_tab; }
+template <int KIND> void env_new(EnvState* e) { env_init<KIND>(*e); }
+template <int KIND> void env_rst(EnvState* e, const float* inject, float* obs) {
+    SimParams p{}; float u[8]; draw8(p, 0, (uint32_t)e->rngc, 1, inject, u); e->rngc++; env_reset<KIND>(*e, u, tab(), obs);
+}
+template <int KIND> void env_stp(EnvState* e, const SimParams& p, const float* a, const float* inject, float* obs, float* tobs, float* rew, int* done, int* trunc) {
+    StepResult r = env_step_vec<KIND>(*e, a, p, p.env_id_offset, inject, tab(), obs, tobs);
+    *rew = r.reward; *done = r.done; *trunc = r.trunc_only;
+}
+}
+#define KSWITCH(kind, fn, ...) switch (kind) { case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; default: fn<5>(__VA_ARGS__); }
+extern "C" {
+void* hc_env_new(int kind) { EnvState* e = new EnvState; KSWITCH(kind, env_new, e); return e; }
+void hc_env_free(void* e) { delete (EnvState*)e; }
+void hc_env_reset(void* e, int kind, const float* inject, float* obs) { KSWITCH(kind, env_rst, (EnvState*)e, inject, obs); }
+void hc_env_step(void* e, int kind, unsigned flags, int iters, int citers, int max_steps, const float* a, const float* inject,
+                 float* obs, float* tobs, float* rew, int* done, int* trunc) {
+    SimParams p{}; p.n = 1; p.flags = flags; p.solver_iters = iters; p.contact_iters = citers; p.frame_skip = 16; p.max_episode_steps = max_steps;
+    KSWITCH(kind, env_stp, (EnvState*)e, p, a, inject, obs, tobs, rew, done, trunc);
+}
+void hc_env_qpos(void* ev, double* qpos13, double* qvel12) {
+    EnvState* e = (EnvState*)ev;
+    for (int i = 0; i < 6; i++) { qpos13[i] = e->q[i]; qvel12[i] = e->v[i]; qvel12[6+i] = e->cube.vel[i]; }
+    for (int i = 0; i < 3; i++) qpos13[6+i] = e->cube.pos[i];
+    for (int i = 0; i < 4; i++) qpos13[9+i] = e->cube.quat[i];
+}
+}

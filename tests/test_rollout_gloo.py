@@ -1,0 +1,82 @@
+"""The N > 1 path on CPU: world_size 2 over gloo.  Covers (a) the one collective of the path -- the rollout gather to the
+learner rank and the policy broadcast back -- and (b) the sharding contract: rank r steps global envs [rN, (r+1)N) with
+`env_id_offset = rN`, so a sharded run reproduces the unsharded one env by env.  (b) is exercised here with the CPU
+oracle standing in for the simulator (same Philox keying as the device; the GPU version of the same property is
+tests/test_gpu_parity.py::test_full_size_properties)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_local, T, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import so100_oracle as O
+        from so100_mujoco_rl_amd.rollout import RolloutChunk, gather_rollout, broadcast_policy, shard_range
+        total = n_local * world
+        lo, hi = shard_range(total, rank, world)
+        assert hi - lo == n_local
+        flags = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_CUBE_PINNED
+        envs = O.OracleBatch(1, n_local, flags, 3, seed=77, env_id0=lo)
+        obs = envs.reset().copy()
+        rs = np.random.RandomState(5)
+        acts_all = rs.uniform(-1, 1, (T, total, 6)).astype(np.float32)
+        chunk = RolloutChunk(T, n_local, 15, "cpu")
+        for t in range(T):
+            a = acts_all[t, lo:hi]
+            o2, r, term, trunc = envs.step(a)
+            chunk.write(t, torch.from_numpy(obs), torch.from_numpy(a), torch.from_numpy(r.copy()),
+                        torch.from_numpy((term | trunc).astype(np.float32)), torch.full((n_local,), float(rank)), torch.zeros(n_local))
+            obs = o2.copy()
+        full = gather_rollout(chunk.buf, dst=0)
+        w = torch.full((4,), float(rank + 1)); broadcast_policy([w], src=0)
+        assert torch.all(w == 1.0)
+        if rank == 0:
+            q.put(("ok", full.numpy(), acts_all))
+        else:
+            assert full is None
+            q.put(("ok", None, None))
+    except Exception as e:                                   # pragma: no cover
+        import traceback
+        q.put(("err", traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rollout_gather_world2():
+    from oracle import so100_oracle as O
+    from so100_mujoco_rl_amd.rollout import RolloutChunk
+    world, n_local, T = 2, 6, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_local, T, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(r[0] == "ok" for r in res), [r[1] for r in res if r[0] != "ok"]
+    full, acts_all = [(r[1], r[2]) for r in res if r[1] is not None][0]
+    total = world * n_local
+    assert full.shape == (T, total, 25)
+    # unsharded single-process run of the same global envs
+    flags = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_CUBE_PINNED
+    envs = O.OracleBatch(1, total, flags, 3, seed=77, env_id0=0)
+    obs = envs.reset().copy()
+    u = RolloutChunk(T, total, 15, "cpu").unpack(torch.from_numpy(full))
+    for t in range(T):
+        np.testing.assert_array_equal(u["obs"][t].numpy(), obs)                       # rank order == env order
+        np.testing.assert_array_equal(u["actions"][t].numpy(), acts_all[t])
+        o2, r, term, trunc = envs.step(acts_all[t])
+        np.testing.assert_array_equal(u["rewards"][t].numpy(), r)
+        obs = o2.copy()
+    np.testing.assert_array_equal(u["values"][0].numpy(), np.repeat(np.arange(world, dtype=np.float32), n_local))
