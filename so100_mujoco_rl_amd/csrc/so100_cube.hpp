@@ -22,6 +22,10 @@
 
 namespace so100 {
 
+#if !defined(__HIPCC__)
+static long g_dbg_newton_iters = 0, g_dbg_newton_ls = 0;      // host-only instrumentation (tests/_hostcheck)
+#endif
+
 template <typename T> struct Cube {
     T pos[3], quat[4], vel[6];     // vel = (linear, world frame; angular, body frame) like MuJoCo qvel
     T warm[6];                     // previous x = qacc - qacc_smooth (Newton warm start)
@@ -191,6 +195,9 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
             const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
             for (int it = 0; it < iters; it++) {
                 T g[6], Hm[21], Dinv[6], dx[6];
+#if !defined(__HIPCC__)
+                g_dbg_newton_iters++;
+#endif
                 cube_rows_eval(r, x, g, Hm, true);
 #pragma unroll
                 for (int i = 0; i < 6; i++) dx[i] = -g[i];
@@ -198,7 +205,7 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
                 ldl6_solve(Hm, Dinv, dx);
                 // converged when the Newton step no longer changes the acceleration (fp32: ~1e-6 g): at rest the
                 // warm start is already the optimum, so a resting cube costs one gradient/Hessian evaluation
-                const T tol = sizeof(T) == 4 ? T(2e-5) : T(1e-11);
+                const T tol = sizeof(T) == 4 ? T(1e-4) : T(1e-11);          // fp32: 1e-5 g, above the ~1e-5 m/s^2 round-off floor
                 const T dmax = tmax(tmax(tabs(dx[0]), tabs(dx[1])), tabs(dx[2]));
                 const T amax = tmax(tmax(tabs(dx[3]), tabs(dx[4])), tabs(dx[5]))*T(so100g::CUBE_HALF);
                 if (tmax(dmax, amax) < tol) {
@@ -218,11 +225,14 @@ SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int i
 #pragma unroll 1
                 for (int ls = 0; ls < 10; ls++) {
                     cube_phi(r, j0, jd, q1, q2, alpha, d1, d2);
+#if !defined(__HIPCC__)
+                    g_dbg_newton_ls++;
+#endif
                     if (d1 < T(0)) lo = alpha; else hi = alpha;
                     T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
                     const bool inside = an > lo && (hi < T(0) || an < hi);
                     if (!inside) an = hi < T(0) ? T(2)*alpha : T(0.5)*(lo + hi);
-                    if (tabs(an - alpha) <= T(1e-6)*tabs(alpha)) { alpha = an; break; }
+                    if (tabs(an - alpha) <= (sizeof(T) == 4 ? T(1e-3) : T(1e-9))*tabs(alpha)) { alpha = an; break; }
                     alpha = an;
                 }
 #pragma unroll

@@ -50,6 +50,7 @@ void hc_poses_f(const double* q, double* out) { poses<float>(q, out); }
 void hc_cube_d(double* p, double* q, double* v, double* w, const double* a, unsigned fg, int it, int n) { cube<double>(p, q, v, w, a, fg, it, n); }
 void hc_cube_f(double* p, double* q, double* v, double* w, const double* a, unsigned fg, int it, int n) { cube<float>(p, q, v, w, a, fg, it, n); }
 void hc_sincos_f(float x, float* s, float* c) { tsincos<float>(x, *s, *c); }
+void hc_dbg_counters(long* out) { out[0] = g_dbg_newton_iters; out[1] = g_dbg_newton_ls; }
 }
 
 // ---- the full task layer (so100_task.hpp) on the host, fp32, one env ------------------------------------------------
