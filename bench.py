@@ -5,7 +5,9 @@ One "step" = one vectorised env step of the rollout loop on every rank: policy f
 separate 2x64 tanh towers for pi and V, state-independent log-std Gaussian), action sampling + clipping, the fused
 HIP env step (reward -> ctrl -> 16 physics substeps -> obs -> TimeLimit -> auto-reset), and the write of
 obs/action/reward/done/value/log-prob into the on-device rollout buffer; every ROLLOUT_T steps the rollout chunk is
-gathered to the learner rank over RCCL (N > 1 only).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
+gathered to the learner rank over RCCL (N > 1 only).  Default collector: two launches per step -- the fused policy
+kernel (so100_policy_forward) and the fused env step -- with no PyTorch op in the loop; `--policy torch` runs the
+same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
 GPU, contact disabled / no constraint solver (cube pinned), synthetic randomized-reset batches, random-init policy.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (so100_step_fused) with the algorithmic
@@ -88,6 +90,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_reference", "env02_reference", "env05_reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--policy", default="fused", choices=["fused", "torch"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
@@ -115,15 +118,28 @@ def main():
     gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
     noise = torch.empty(n, 6, device=dev)
 
+    act = torch.zeros(n, 6, device=dev)
+    if args.policy == "fused":
+        sim.set_policy({"pi_w0": pol.pi[0][0].t().contiguous(), "pi_b0": pol.pi[0][1], "pi_w1": pol.pi[1][0].t().contiguous(), "pi_b1": pol.pi[1][1],
+                        "mu_w": pol.mu[0].t().contiguous(), "mu_b": pol.mu[1], "log_std": pol.log_std,
+                        "vf_w0": pol.vf[0][0].t().contiguous(), "vf_b0": pol.vf[0][1], "vf_w1": pol.vf[1][0].t().contiguous(), "vf_b1": pol.vf[1][1],
+                        "v_w": pol.v[0].t().contiguous(), "v_b": pol.v[1]})
+    counter = [0]
+
     def vec_step(t):
-        noise.normal_(generator=g)
-        act, value, logp = pol.forward(obs, noise)
         row = chunk[t % T]
-        row[:, :sim.obs_dim] = obs
-        act = act.clamp_(-1.0, 1.0)
-        ob, rew, done, trunc = sim.step(act)
-        row[:, sim.obs_dim:sim.obs_dim + 6] = act
-        row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
+        if args.policy == "fused":
+            sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
+            sim.step(act, rollout_row=row)                                     # reward | done -> row
+            counter[0] += 1
+        else:
+            noise.normal_(generator=g)
+            a, value, logp = pol.forward(sim.obs, noise)
+            row[:, :sim.obs_dim] = sim.obs
+            row[:, sim.obs_dim:sim.obs_dim + 6] = a
+            a = a.clamp_(-1.0, 1.0)
+            ob, rew, done, trunc = sim.step(a)
+            row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
         if world > 1 and (t + 1) % T == 0:
             dist.gather(chunk, gathered, dst=0)              # RCCL: rollout chunk -> learner rank
 
@@ -145,6 +161,7 @@ def main():
 
     # dominant kernel alone: HIP events on the launch stream around back-to-back so100_step launches
     act = torch.rand(n, 6, device=dev) * 2 - 1
+    act = act.contiguous()
     for _ in range(20):
         sim.step(act)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -165,7 +182,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: Env{kind:02d} x {n} envs/GPU, frame_skip 16, "
                                    + ("contact disabled, no constraint solver (BASELINE.json configs[1])" if args.workload == "env01_free" else "friction-loss + limits + cube/floor contact")
-                                   + ", SB3-MlpPolicy-shaped rollout, randomized resets, staggered episodes",
+                                   + ", SB3-MlpPolicy-shaped rollout (" + args.policy + " policy), randomized resets, staggered episodes",
                        "envs_per_gpu": n, "rollout_chunk": T, "parallelism": f"env-sharded x{world}, RCCL gather per chunk" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "kernel": "so100_step_fused", "kernel_ms": kern_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP,

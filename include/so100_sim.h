@@ -78,7 +78,37 @@ typedef struct {
     float*       ep_return_dev;    /* [N] Monitor's info["episode"]["r"], written where done; nullable */
     int32_t*     ep_length_dev;    /* [N] Monitor's info["episode"]["l"], written where done; nullable */
     const float* inject_dev;       /* [N][SO100_NINJECT] uniforms replacing the device RNG (parity tests); nullable */
+    float*       rollout_row_dev;  /* [N][obs_dim+10] row of a rollout buffer (layout: so100_policy_io); the step writes
+                                      reward -> column obs_dim+6 and done (0/1) -> column obs_dim+7; nullable */
 } so100_step_io;
+
+/* ---- rollout-side helper (caller of the hot path) ------------------------------------------
+ * Fused SB3 "MlpPolicy" forward for a Box action space (ref: main.py:56-64 -> stable_baselines3 PPO("MlpPolicy"):
+ * separate 2x64 tanh towers for pi and V, state-independent log_std), Gaussian sampling, log-prob, clip to [-1,1]
+ * and the rollout-buffer write, in one launch.  Weights are PyTorch nn.Linear tensors (weight[out][in], row-major),
+ * i.e. the policy's state_dict entries named in the comments. */
+typedef struct {
+    const float *pi_w0, *pi_b0;    /* mlp_extractor.policy_net.0.{weight[64][obs_dim], bias[64]} */
+    const float *pi_w1, *pi_b1;    /* mlp_extractor.policy_net.2.{weight[64][64], bias[64]}      */
+    const float *mu_w, *mu_b;      /* action_net.{weight[6][64], bias[6]}                        */
+    const float *log_std;          /* log_std[6]                                                 */
+    const float *vf_w0, *vf_b0;    /* mlp_extractor.value_net.0.{weight[64][obs_dim], bias[64]}  */
+    const float *vf_w1, *vf_b1;    /* mlp_extractor.value_net.2.{weight[64][64], bias[64]}       */
+    const float *v_w, *v_b;        /* value_net.{weight[1][64], bias[1]}                         */
+} so100_policy_weights;
+
+typedef struct {
+    const float* obs_dev;          /* [N][obs_dim]                                                         */
+    const float* noise_dev;        /* [N][6] standard normals replacing the device RNG; nullable            */
+    float*       act_env_dev;      /* [N][6] clipped to [-1,1] (what so100_step consumes)                   */
+    float*       act_raw_dev;      /* [N][6] unclipped sample (what SB3 stores); nullable                   */
+    float*       value_dev;        /* [N]; nullable                                                         */
+    float*       logp_dev;         /* [N]; nullable                                                         */
+    float*       rollout_row_dev;  /* [N][obs_dim+10] = obs | raw action(6) | reward | done | value | logp; nullable */
+} so100_policy_io;
+
+int  so100_policy_forward(so100_sim* sim, const so100_policy_weights* w, const so100_policy_io* io,
+                          uint32_t step_counter, void* hip_stream);
 
 int  so100_abi_version(void);
 int  so100_obs_dim(int32_t env_kind);                     /* ref: env_base_01.py:63-75 (15), env_base_02.py:56-69 (8) */

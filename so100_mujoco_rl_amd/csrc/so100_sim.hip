@@ -13,6 +13,7 @@
 #include <new>
 #include "../../include/so100_sim.h"
 #include "so100_task.hpp"
+#include "so100_policy.hpp"
 
 namespace {
 
@@ -50,6 +51,7 @@ struct StepPtrs {
     float* state; const float* start_tab;
     const float* act; float* obs; float* rew; uint8_t* done; uint8_t* trunc; float* tobs; float* ep_ret; int32_t* ep_len;
     const float* inject;
+    float* rollout_row;
 };
 
 // K1: one fused env step (reward -> ctrl -> 16 x {FK, CRB, RNE, servo, rows, block-PGS / Newton, Euler} -> obs
@@ -74,6 +76,10 @@ __global__ void __launch_bounds__(WG) so100_step_fused(SimParams p, StepPtrs io)
 #pragma unroll
     for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];
     io.rew[env] = r.reward;
+    if (io.rollout_row) {
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 6] = r.reward;
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? 1.0f : 0.0f;
+    }
     io.done[env] = r.done ? 1 : 0;
     io.trunc[env] = r.trunc_only ? 1 : 0;
     if (r.done) {
@@ -257,8 +263,28 @@ int so100_step(so100_sim* s, const so100_step_io* io, void* stream) {
     StepPtrs p;
     p.state = s->state; p.start_tab = s->start_tab;
     p.act = io->act_dev; p.obs = io->obs_dev; p.rew = io->rew_dev; p.done = io->done_dev; p.trunc = io->trunc_dev;
-    p.tobs = io->terminal_obs_dev; p.ep_ret = io->ep_return_dev; p.ep_len = io->ep_length_dev; p.inject = io->inject_dev;
+    p.tobs = io->terminal_obs_dev; p.ep_ret = io->ep_return_dev; p.ep_len = io->ep_length_dev; p.inject = io->inject_dev; p.rollout_row = io->rollout_row_dev;
     return DISPATCH_KIND(s->cfg.env_kind, launch_step)(s, p, (hipStream_t)stream);
+}
+
+int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so100_policy_io* io, uint32_t step_counter, void* stream) {
+    if (!s || !w || !io) return fail(SO100_E_INVALID, "so100_policy_forward: null argument%s");
+    if (!io->obs_dev || !io->act_env_dev) return fail(SO100_E_INVALID, "so100_policy_forward: obs and act_env pointers are required%s");
+    const float* const* wp = reinterpret_cast<const float* const*>(w);
+    for (int i = 0; i < 13; i++) if (!wp[i]) return fail(SO100_E_INVALID, "so100_policy_forward: null weight pointer%s");
+    DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_policy_forward: cannot select the device%s");
+    PolicyWeights pw; static_assert(sizeof(PolicyWeights) == sizeof(so100_policy_weights), "layout");
+    memcpy(&pw, w, sizeof pw);
+    PolicyIO pio; pio.obs = io->obs_dev; pio.noise = io->noise_dev; pio.act_env = io->act_env_dev; pio.act_raw = io->act_raw_dev;
+    pio.value = io->value_dev; pio.logp = io->logp_dev; pio.rollout_row = io->rollout_row_dev;
+    const dim3 grid((unsigned)((s->prm.n + 63)/64)), block(256);
+    if (s->cfg.env_kind <= 2)
+        hipLaunchKernelGGL(so100_policy_forward_kernel<15>, grid, block, 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+    else
+        hipLaunchKernelGGL(so100_policy_forward_kernel<8>, grid, block, 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+    HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
+    return 0;
 }
 
 int so100_get_state(so100_sim* s, float* qpos_dev, float* qvel_dev, void* stream) {

@@ -33,12 +33,30 @@ class Config(C.Structure):
 class StepIO(C.Structure):
     _fields_ = [("act_dev", C.c_void_p), ("obs_dev", C.c_void_p), ("rew_dev", C.c_void_p), ("done_dev", C.c_void_p),
                 ("trunc_dev", C.c_void_p), ("terminal_obs_dev", C.c_void_p), ("ep_return_dev", C.c_void_p),
-                ("ep_length_dev", C.c_void_p), ("inject_dev", C.c_void_p)]
+                ("ep_length_dev", C.c_void_p), ("inject_dev", C.c_void_p), ("rollout_row_dev", C.c_void_p)]
+
+
+POLICY_TENSORS = ["pi_w0", "pi_b0", "pi_w1", "pi_b1", "mu_w", "mu_b", "log_std", "vf_w0", "vf_b0", "vf_w1", "vf_b1", "v_w", "v_b"]
+# the SB3 ActorCriticPolicy state_dict entry behind each pointer
+SB3_STATE_DICT_KEYS = {"pi_w0": "mlp_extractor.policy_net.0.weight", "pi_b0": "mlp_extractor.policy_net.0.bias",
+                       "pi_w1": "mlp_extractor.policy_net.2.weight", "pi_b1": "mlp_extractor.policy_net.2.bias",
+                       "mu_w": "action_net.weight", "mu_b": "action_net.bias", "log_std": "log_std",
+                       "vf_w0": "mlp_extractor.value_net.0.weight", "vf_b0": "mlp_extractor.value_net.0.bias",
+                       "vf_w1": "mlp_extractor.value_net.2.weight", "vf_b1": "mlp_extractor.value_net.2.bias",
+                       "v_w": "value_net.weight", "v_b": "value_net.bias"}
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in POLICY_TENSORS]
+
+
+class PolicyIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("obs_dev", "noise_dev", "act_env_dev", "act_raw_dev", "value_dev", "logp_dev", "rollout_row_dev")]
 
 
 EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_create",
            "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
-           "so100_set_field", "so100_last_error"]
+           "so100_set_field", "so100_last_error", "so100_policy_forward"]
 
 
 def build(verbose=False):
@@ -69,6 +87,7 @@ def load():
         L.so100_destroy.restype = None
         L.so100_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_step.argtypes = [C.c_void_p, C.POINTER(StepIO), C.c_void_p]
+        L.so100_policy_forward.argtypes = [C.c_void_p, C.POINTER(PolicyWeights), C.POINTER(PolicyIO), C.c_uint32, C.c_void_p]
         L.so100_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -140,9 +159,11 @@ class So100Sim:
         _check(self.L.so100_reset(self.h, m, i, self.obs.data_ptr(), self._stream()), "so100_reset")
         return self.obs
 
-    def step(self, actions, inject=None):
-        """actions: float32 [N,6] on the device.  Returns views of the handle's output tensors."""
+    def step(self, actions, inject=None, rollout_row=None):
+        """actions: float32 [N,6] on the device.  Returns views of the handle's output tensors.
+        rollout_row: optional float32 [N, obs_dim+10] row of a rollout buffer; reward/done are written into it."""
         io = self._io
+        io.rollout_row_dev = _ptr(rollout_row, torch.float32, (self.n, self.obs_dim + 10), self.device)
         io.act_dev = _ptr(actions, torch.float32, (self.n, 6), self.device)
         io.obs_dev = self.obs.data_ptr(); io.rew_dev = self.rew.data_ptr()
         io.done_dev = self.done.data_ptr(); io.trunc_dev = self.trunc.data_ptr()
@@ -151,6 +172,27 @@ class So100Sim:
         io.inject_dev = _ptr(inject, torch.float32, (self.n, NINJECT), self.device)
         _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
         return self.obs, self.rew, self.done, self.trunc
+
+    def set_policy(self, tensors):
+        """tensors: dict name -> float32 device tensor (names: POLICY_TENSORS; SB3 keys: SB3_STATE_DICT_KEYS)."""
+        od = self.obs_dim
+        shapes = {"pi_w0": (64, od), "pi_b0": (64,), "pi_w1": (64, 64), "pi_b1": (64,), "mu_w": (6, 64), "mu_b": (6,), "log_std": (6,),
+                  "vf_w0": (64, od), "vf_b0": (64,), "vf_w1": (64, 64), "vf_b1": (64,), "v_w": (1, 64), "v_b": (1,)}
+        self._policy_tensors = {k: tensors[k] for k in POLICY_TENSORS}          # keep them alive
+        self._pw = PolicyWeights(*[_ptr(tensors[k], torch.float32, shapes[k], self.device) for k in POLICY_TENSORS])
+        self._pio = PolicyIO()
+
+    def policy_forward(self, obs, act_env, step_counter, noise=None, act_raw=None, value=None, logp=None, rollout_row=None):
+        """Fused SB3-MlpPolicy forward + sample + clip (+ rollout-row write): one launch on the current stream."""
+        io = self._pio
+        io.obs_dev = _ptr(obs, torch.float32, (self.n, self.obs_dim), self.device)
+        io.noise_dev = _ptr(noise, torch.float32, (self.n, 6), self.device)
+        io.act_env_dev = _ptr(act_env, torch.float32, (self.n, 6), self.device)
+        io.act_raw_dev = _ptr(act_raw, torch.float32, (self.n, 6), self.device)
+        io.value_dev = _ptr(value, torch.float32, (self.n,), self.device)
+        io.logp_dev = _ptr(logp, torch.float32, (self.n,), self.device)
+        io.rollout_row_dev = _ptr(rollout_row, torch.float32, (self.n, self.obs_dim + 10), self.device)
+        _check(self.L.so100_policy_forward(self.h, C.byref(self._pw), C.byref(io), int(step_counter) & 0xFFFFFFFF, self._stream()), "so100_policy_forward")
 
     def get_state(self):
         qpos = torch.empty(13, self.n, dtype=torch.float32, device=self.device)

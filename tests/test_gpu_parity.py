@@ -267,3 +267,52 @@ def test_full_size_properties(kind, n):
             assert q[i].min() > a - 0.05 and q[i].max() < b + 0.05          # soft limits hold
     nq = torch.linalg.vector_norm(q[9:13], dim=0)
     assert (nq - 1).abs().max() < 1e-5                                      # cube quaternion stays normalised
+
+
+# ---- rollout-side fused policy kernel vs a plain PyTorch fp32 reference of the same op -----------------------------
+def _torch_policy(t, obs, noise):
+    h = torch.tanh(obs @ t["pi_w0"].T + t["pi_b0"]); h = torch.tanh(h @ t["pi_w1"].T + t["pi_b1"])
+    mean = h @ t["mu_w"].T + t["mu_b"]
+    g = torch.tanh(obs @ t["vf_w0"].T + t["vf_b0"]); g = torch.tanh(g @ t["vf_w1"].T + t["vf_b1"])
+    value = (g @ t["v_w"].T + t["v_b"]).squeeze(1)
+    act = mean + t["log_std"].exp() * noise
+    logp = (-0.5 * noise ** 2 - t["log_std"] - 0.9189385332046727).sum(1)
+    return act, value, logp
+
+
+@pytest.mark.parametrize("kind", [1, 5])
+def test_policy_kernel_vs_torch(kind):
+    from so100_mujoco_rl_amd import lib
+    n = 1000                                                   # not a multiple of 64: tail lanes are masked
+    sim = _sim(kind, n, flags=FREE)
+    od = sim.obs_dim
+    g = torch.Generator(device="cuda"); g.manual_seed(kind)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    t = {"pi_w0": rnd(64, od) * 0.3, "pi_b0": rnd(64) * 0.1, "pi_w1": rnd(64, 64) * 0.2, "pi_b1": rnd(64) * 0.1,
+         "mu_w": rnd(6, 64) * 0.2, "mu_b": rnd(6) * 0.1, "log_std": rnd(6) * 0.3,
+         "vf_w0": rnd(64, od) * 0.3, "vf_b0": rnd(64) * 0.1, "vf_w1": rnd(64, 64) * 0.2, "vf_b1": rnd(64) * 0.1,
+         "v_w": rnd(1, 64) * 0.2, "v_b": rnd(1)}
+    t = {k: v.contiguous() for k, v in t.items()}
+    sim.set_policy(t)
+    obs = rnd(n, od).contiguous(); noise = rnd(n, 6).contiguous()
+    act_env = torch.zeros(n, 6, device="cuda"); act_raw = torch.zeros_like(act_env)
+    value = torch.zeros(n, device="cuda"); logp = torch.zeros(n, device="cuda"); row = torch.zeros(n, od + 10, device="cuda")
+    sim.policy_forward(obs, act_env, 0, noise=noise, act_raw=act_raw, value=value, logp=logp, rollout_row=row)
+    a, v, lp = _torch_policy(t, obs, noise)
+    # tolerance: fp32 accumulation order + exp2-based tanh (abs err < 2e-7 per activation)
+    assert (act_raw - a).abs().max() < 2e-5 and (value - v).abs().max() < 2e-5 and (logp - lp).abs().max() < 2e-5
+    assert torch.equal(act_env, act_raw.clamp(-1, 1))
+    assert torch.equal(row[:, :od], obs) and torch.equal(row[:, od:od + 6], act_raw)
+    assert torch.equal(row[:, od + 8], value) and torch.equal(row[:, od + 9], logp)
+    # device RNG: deterministic, depends on the step counter, standard normal
+    sim2 = _sim(kind, 65536, flags=FREE, seed=5); sim2.set_policy(t)
+    o2 = torch.zeros(65536, od, device="cuda"); a1 = torch.zeros(65536, 6, device="cuda"); a2 = torch.zeros_like(a1); a3 = torch.zeros_like(a1)
+    e1 = torch.zeros_like(a1)
+    sim2.policy_forward(o2, e1, 7, act_raw=a1); sim2.policy_forward(o2, e1, 7, act_raw=a2); sim2.policy_forward(o2, e1, 8, act_raw=a3)
+    assert torch.equal(a1, a2) and not torch.equal(a1, a3)
+    mean0, _, _ = _torch_policy(t, o2[:1], torch.zeros(1, 6, device="cuda"))
+    eps = (a1 - mean0) / t["log_std"].exp()
+    assert eps.mean().abs() < 0.01 and (eps.std() - 1).abs() < 0.01 and (eps ** 4).mean().sub(3).abs() < 0.1
+    # the env step fills reward / done into the same rollout row
+    ob, r, d, tr = sim.step(act_env, rollout_row=row)
+    assert torch.equal(row[:, od + 6], r) and torch.equal(row[:, od + 7], d.float())
