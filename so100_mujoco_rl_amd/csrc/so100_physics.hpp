@@ -92,18 +92,51 @@ template <int A, typename T> SO100_HD void rot_axis_T(const T x[3], T s, T c, T 
     const T xb = x[B], xc = x[C];
     y[A] = x[A]; y[B] = c*xb + s*xc; y[C] = -s*xb + c*xc;
 }
+// Compile-time-sparse products with model constants.  The link rotations are (nearly) axis-aligned: five exact
+// zeros per matrix for links 0-4, and most link offsets have a zero x component.  `0.0f * x` cannot be folded by the
+// compiler under IEEE rules, so exact zeros are skipped here with `if constexpr` (x * 1.0f and x * -1.0f fold anyway).
+template <int K, int A, int B, int C_, typename T> SO100_HD T cdot3(T x0, T x1, T x2) {     // sum of LINK_C[K][.] * x.
+    constexpr double a = so100g::LINK_C[K][A], b = so100g::LINK_C[K][B], c = so100g::LINK_C[K][C_];
+    if constexpr (a != 0 && b != 0 && c != 0) return T(a)*x0 + T(b)*x1 + T(c)*x2;
+    else if constexpr (a != 0 && b != 0) return T(a)*x0 + T(b)*x1;
+    else if constexpr (a != 0 && c != 0) return T(a)*x0 + T(c)*x2;
+    else if constexpr (b != 0 && c != 0) return T(b)*x1 + T(c)*x2;
+    else if constexpr (a != 0) return T(a)*x0;
+    else if constexpr (b != 0) return T(b)*x1;
+    else if constexpr (c != 0) return T(c)*x2;
+    else return T(0);
+}
+template <int K, int IA, int IB, typename T> SO100_HD T pdiff(T xa, T xb) {                  // P[IA]*xa - P[IB]*xb
+    constexpr double a = so100g::LINK_P[K][IA], b = so100g::LINK_P[K][IB];
+    if constexpr (a != 0 && b != 0) return T(a)*xa - T(b)*xb;
+    else if constexpr (a != 0) return T(a)*xa;
+    else if constexpr (b != 0) return -(T(b)*xb);
+    else return T(0);
+}
+template <int K, int I, typename T> SO100_HD T pmul(T x) {                                      // P[I] * x
+    constexpr double a = so100g::LINK_P[K][I];
+    if constexpr (a != 0) return T(a)*x; else return T(0);
+}
+template <int K, int I, int J, typename T> SO100_HD T ppmul(T x) {                              // P[I] P[J] * x
+    constexpr double a = so100g::LINK_P[K][I]*so100g::LINK_P[K][J];
+    if constexpr (a != 0) return T(a)*x; else return T(0);
+}
+template <int K, typename T> SO100_HD void pcross(const T v[3], T r[3]) {                    // r = p_K x v
+    const T v0 = v[0], v1 = v[1], v2 = v[2];
+    r[0] = pdiff<K, 1, 2>(v2, v1); r[1] = pdiff<K, 2, 0>(v0, v2); r[2] = pdiff<K, 0, 1>(v1, v0);
+}
+template <int K, typename T> SO100_HD void crossp(const T v[3], T r[3]) {                    // r = v x p_K
+    const T v0 = v[0], v1 = v[1], v2 = v[2];
+    r[0] = pdiff<K, 2, 1>(v1, v2); r[1] = pdiff<K, 0, 2>(v2, v0); r[2] = pdiff<K, 1, 0>(v0, v1);
+}
 // constant link rotation C_K (child->parent) and its transpose
 template <int K, typename T> SO100_HD void cmat(const T x[3], T y[3]) {
     const T x0 = x[0], x1 = x[1], x2 = x[2];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        y[i] = T(so100g::LINK_C[K][3*i])*x0 + T(so100g::LINK_C[K][3*i+1])*x1 + T(so100g::LINK_C[K][3*i+2])*x2;
+    y[0] = cdot3<K, 0, 1, 2>(x0, x1, x2); y[1] = cdot3<K, 3, 4, 5>(x0, x1, x2); y[2] = cdot3<K, 6, 7, 8>(x0, x1, x2);
 }
 template <int K, typename T> SO100_HD void cmat_T(const T x[3], T y[3]) {
     const T x0 = x[0], x1 = x[1], x2 = x[2];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        y[i] = T(so100g::LINK_C[K][i])*x0 + T(so100g::LINK_C[K][3+i])*x1 + T(so100g::LINK_C[K][6+i])*x2;
+    y[0] = cdot3<K, 0, 3, 6>(x0, x1, x2); y[1] = cdot3<K, 1, 4, 7>(x0, x1, x2); y[2] = cdot3<K, 2, 5, 8>(x0, x1, x2);
 }
 // parent coords -> link K coords (E_K^T) and back (E_K), E_K = C_K Rot(axis_K, q_K)
 template <int K, typename T> SO100_HD void to_child(const T x[3], T s, T c, T y[3]) {
@@ -140,6 +173,22 @@ template <typename T> SO100_HD void sym_similarity(const T R[9], const T A[6], T
     Bm[4] = t[0]*R[6] + t[1]*R[7] + t[2]*R[8];
     Bm[5] = t[3]*R[6] + t[4]*R[7] + t[5]*R[8];
 }
+// B = C_K A C_K^T with the constant, sparse link rotation C_K
+template <int K, typename T> SO100_HD void sym_similarity_c(const T A[6], T Bm[6]) {
+    T t[9];                                                   // t = C A
+#define SO100_ROW(i) \
+    t[3*i]   = cdot3<K, 3*i, 3*i+1, 3*i+2>(A[0], A[3], A[4]); \
+    t[3*i+1] = cdot3<K, 3*i, 3*i+1, 3*i+2>(A[3], A[1], A[5]); \
+    t[3*i+2] = cdot3<K, 3*i, 3*i+1, 3*i+2>(A[4], A[5], A[2]);
+    SO100_ROW(0) SO100_ROW(1) SO100_ROW(2)
+#undef SO100_ROW
+    Bm[0] = cdot3<K, 0, 1, 2>(t[0], t[1], t[2]);
+    Bm[1] = cdot3<K, 3, 4, 5>(t[3], t[4], t[5]);
+    Bm[2] = cdot3<K, 6, 7, 8>(t[6], t[7], t[8]);
+    Bm[3] = cdot3<K, 3, 4, 5>(t[0], t[1], t[2]);
+    Bm[4] = cdot3<K, 6, 7, 8>(t[0], t[1], t[2]);
+    Bm[5] = cdot3<K, 6, 7, 8>(t[3], t[4], t[5]);
+}
 // similarity by a rotation about coordinate axis A: B = Rot A Rot^T
 template <int AX, typename T> SO100_HD void sym_rot_axis(const T A[6], T s, T c, T Bm[6]) {
     constexpr int B = (AX + 1) % 3, C = (AX + 2) % 3;
@@ -167,10 +216,9 @@ template <int K, typename T> struct LinkFwd {            // RNEA forward step fo
     SO100_HD static void run(const T s[6], const T c[6], const T v[6], T w[3], T wd[3], T a[3],
                              T f[6][3], T n[6][3]) {
         constexpr int AX = so100g::LINK_AXIS[K];
-        const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
         // acceleration of this link's origin, in parent coords: a + wd x p + w x (w x p)
         T t1[3], t2[3], ao[3];
-        cross(wd, p, t1); cross(w, p, t2); cross(w, t2, t2);
+        crossp<K>(wd, t1); crossp<K>(w, t2); cross(w, t2, t2);
         ao[0] = a[0] + t1[0] + t2[0]; ao[1] = a[1] + t1[1] + t2[1]; ao[2] = a[2] + t1[2] + t2[2];
         T wc[3], wdc[3];
         to_child<K>(w, s[K], c[K], wc);
@@ -201,11 +249,10 @@ template <int K, typename T> struct LinkBwd {            // RNEA backward step: 
     SO100_HD static void run(const T s[6], const T c[6], T f[6][3], T n[6][3], T bias[6]) {
         bias[K] = n[K][so100g::LINK_AXIS[K]];
         if constexpr (K > 0) {
-            const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
             T fp[3], np[3], t[3];
             to_parent<K>(f[K], s[K], c[K], fp);
             to_parent<K>(n[K], s[K], c[K], np);
-            cross(p, fp, t);
+            pcross<K>(fp, t);
 #pragma unroll
             for (int i = 0; i < 3; i++) { f[K-1][i] += fp[i]; n[K-1][i] += np[i] + t[i]; }
         }
@@ -231,36 +278,33 @@ template <int K, typename T> struct LinkCrb {
         }
         // ---- accumulate into the parent
         if constexpr (K > 0) {
-            const T p[3] = { T(so100g::LINK_P[K][0]), T(so100g::LINK_P[K][1]), T(so100g::LINK_P[K][2]) };
             T hp[3], Ir[6], Ip[6];
             to_parent<K>(cmp[K].h, s[K], c[K], hp);
             sym_rot_axis<AX>(cmp[K].I, s[K], c[K], Ir);
-            T Cm[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) Cm[i] = T(so100g::LINK_C[K][i]);
-            sym_similarity(Cm, Ir, Ip);
+            sym_similarity_c<K>(Ir, Ip);
             const T m = cmp[K].m;
-            const T pp = dot(p, p), ph = dot(p, hp);
-            const T dg = m*pp + T(2)*ph;
+            constexpr double pp_c = so100g::LINK_P[K][0]*so100g::LINK_P[K][0] + so100g::LINK_P[K][1]*so100g::LINK_P[K][1]
+                                  + so100g::LINK_P[K][2]*so100g::LINK_P[K][2];
+            const T ph = pmul<K, 0>(hp[0]) + pmul<K, 1>(hp[1]) + pmul<K, 2>(hp[2]);
+            const T dg = m*T(pp_c) + T(2)*ph;
             Composite<T>& P = cmp[K-1];
-            P.I[0] += Ip[0] + dg - m*p[0]*p[0] - T(2)*p[0]*hp[0];
-            P.I[1] += Ip[1] + dg - m*p[1]*p[1] - T(2)*p[1]*hp[1];
-            P.I[2] += Ip[2] + dg - m*p[2]*p[2] - T(2)*p[2]*hp[2];
-            P.I[3] += Ip[3] - m*p[0]*p[1] - p[0]*hp[1] - hp[0]*p[1];
-            P.I[4] += Ip[4] - m*p[0]*p[2] - p[0]*hp[2] - hp[0]*p[2];
-            P.I[5] += Ip[5] - m*p[1]*p[2] - p[1]*hp[2] - hp[1]*p[2];
-            P.h[0] += hp[0] + m*p[0]; P.h[1] += hp[1] + m*p[1]; P.h[2] += hp[2] + m*p[2];
+            P.I[0] += Ip[0] + dg - ppmul<K, 0, 0>(m) - T(2)*pmul<K, 0>(hp[0]);
+            P.I[1] += Ip[1] + dg - ppmul<K, 1, 1>(m) - T(2)*pmul<K, 1>(hp[1]);
+            P.I[2] += Ip[2] + dg - ppmul<K, 2, 2>(m) - T(2)*pmul<K, 2>(hp[2]);
+            P.I[3] += Ip[3] - ppmul<K, 0, 1>(m) - pmul<K, 0>(hp[1]) - pmul<K, 1>(hp[0]);
+            P.I[4] += Ip[4] - ppmul<K, 0, 2>(m) - pmul<K, 0>(hp[2]) - pmul<K, 2>(hp[0]);
+            P.I[5] += Ip[5] - ppmul<K, 1, 2>(m) - pmul<K, 1>(hp[2]) - pmul<K, 2>(hp[1]);
+            P.h[0] += hp[0] + pmul<K, 0>(m); P.h[1] += hp[1] + pmul<K, 1>(m); P.h[2] += hp[2] + pmul<K, 2>(m);
             P.m += m;
         }
     }
     // carry (f, n) from frame J+1 to frame J for J = K-1 .. 0 and read M[K][J]
     template <int J1> SO100_HD static void walk(const T s[6], const T c[6], T f[3], T n[3], T M[21]) {
         if constexpr (J1 > 0) {
-            const T p[3] = { T(so100g::LINK_P[J1][0]), T(so100g::LINK_P[J1][1]), T(so100g::LINK_P[J1][2]) };
             T fp[3], np[3], t[3];
             to_parent<J1>(f, s[J1], c[J1], fp);
             to_parent<J1>(n, s[J1], c[J1], np);
-            cross(p, fp, t);
+            pcross<J1>(fp, t);
             f[0] = fp[0]; f[1] = fp[1]; f[2] = fp[2];
             n[0] = np[0] + t[0]; n[1] = np[1] + t[1]; n[2] = np[2] + t[2];
             M[K*(K+1)/2 + (J1-1)] = n[so100g::LINK_AXIS[J1-1]];
