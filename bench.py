@@ -173,6 +173,16 @@ def main():
     e1.record(); torch.cuda.synchronize(dev)
     kern_ms = e0.elapsed_time(e1) / reps
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be collected from inside this process; the
+    # committed PMC pass (profiles/r01_c_pmc_summary.json, same workload / batch size) is quoted when it matches.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")))
+        if args.workload == "env01_free" and n == 4096:
+            traffic = [v for k, v in pmc["kernels"].items() if "step_fused" in k][0]["hbm_traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
+
     if rank == 0:
         value = world * n * args.steps / dt
         achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
@@ -185,7 +195,7 @@ def main():
                                    + ", SB3-MlpPolicy-shaped rollout (" + args.policy + " policy), randomized resets, staggered episodes",
                        "envs_per_gpu": n, "rollout_chunk": T, "parallelism": f"env-sharded x{world}, RCCL gather per chunk" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "so100_step_fused", "kernel_ms": kern_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP,
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)", "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n, "kernel": "so100_step_fused", "kernel_ms": kern_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP,
                          "kernel_env_steps_per_s": n / (kern_ms * 1e-3),
                          "valu": {"achieved_tflops": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},

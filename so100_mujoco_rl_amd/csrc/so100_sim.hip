@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 #include "../../include/so100_sim.h"
 #include "so100_task.hpp"
@@ -278,11 +279,13 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
     memcpy(&pw, w, sizeof pw);
     PolicyIO pio; pio.obs = io->obs_dev; pio.noise = io->noise_dev; pio.act_env = io->act_env_dev; pio.act_raw = io->act_raw_dev;
     pio.value = io->value_dev; pio.logp = io->logp_dev; pio.rollout_row = io->rollout_row_dev;
-    const dim3 grid((unsigned)((s->prm.n + 63)/64)), block(256);
-    if (s->cfg.env_kind <= 2)
-        hipLaunchKernelGGL(so100_policy_forward_kernel<15>, grid, block, 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
-    else
-        hipLaunchKernelGGL(so100_policy_forward_kernel<8>, grid, block, 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+    const dim3 grid((unsigned)((s->prm.n + 63)/64));
+    static const int nw = []{ const char* e = getenv("SO100_POLICY_WAVES"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
+#define SO100_LAUNCH_POLICY(OD, NW) hipLaunchKernelGGL((so100_policy_forward_kernel<OD, NW>), grid, dim3(64*NW), 0, (hipStream_t)stream, \
+        s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter)
+    if (s->cfg.env_kind <= 2) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
+    else                      { if (nw == 4) SO100_LAUNCH_POLICY(8, 4);  else if (nw == 8) SO100_LAUNCH_POLICY(8, 8);  else SO100_LAUNCH_POLICY(8, 16); }
+#undef SO100_LAUNCH_POLICY
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }
