@@ -304,6 +304,7 @@ int so100_set_state(so100_sim* s, const float* qpos_dev, const float* qvel_dev, 
     const size_t n = (size_t)s->prm.n;
     HIP_TRY(hipMemcpyAsync(s->state + (size_t)SF_QPOS0*n, qpos_dev, 13*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
     HIP_TRY(hipMemcpyAsync(s->state + (size_t)SF_QVEL0*n, qvel_dev, 12*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
+    HIP_TRY(hipMemsetAsync(s->state + (size_t)SF_qc0*n, 0, 6*n*sizeof(float), (hipStream_t)stream), SO100_E_LAUNCH);   // new q: drop the compensation
     return 0;
 }
 int so100_get_field(so100_sim* s, int32_t field, void* out_dev, void* stream) {

@@ -31,6 +31,7 @@ struct EnvState {
     Cube<float> cube;           // pos, quat, vel, Newton warm start     (qpos[6:13], qvel[6:12])
     float v[6];                 // arm joint velocities                  (qvel[0:6])
     float ff[6], fl[6];         // friction-loss / limit row forces (warm start)
+    float qc[6];                // Kahan compensation of the joint-angle integration
     float ee[3], wrist_z, cx[3];// stale end effector, wrist height, cube xpos (Q1)
     int   nsub, elapsed, bits, rngc;
     float epret; int eplen;
@@ -54,6 +55,7 @@ struct EnvState {
     X(fl0, fl[0], f, 0) X(fl1, fl[1], f, 0) X(fl2, fl[2], f, 0) X(fl3, fl[3], f, 0) X(fl4, fl[4], f, 0) X(fl5, fl[5], f, 0) \
     X(cw0, cube.warm[0], f, 0) X(cw1, cube.warm[1], f, 0) X(cw2, cube.warm[2], f, 0) \
     X(cw3, cube.warm[3], f, 0) X(cw4, cube.warm[4], f, 0) X(cw5, cube.warm[5], f, 0) \
+    X(qc0, qc[0], f, 0) X(qc1, qc[1], f, 0) X(qc2, qc[2], f, 0) X(qc3, qc[3], f, 0) X(qc4, qc[4], f, 0) X(qc5, qc[5], f, 0) \
     X(substeps, nsub, i, 0) X(elapsed_steps, elapsed, i, 0) X(bits, bits, i, 0) X(rng_counter, rngc, i, 0) \
     X(episode_return, epret, f, 0) X(episode_length, eplen, i, 0) \
     X(ee_x, ee[0], f, 1) X(ee_y, ee[1], f, 1) X(ee_z, ee[2], f, 1) X(wrist_z, wrist_z, f, 1) \
@@ -201,7 +203,7 @@ template <int KIND> SO100_HD void env_init(EnvState& e) {
 template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const float* start_tab, float* obs) {
     // mj_resetData: qpos = qpos0, everything else (velocities, warm starts, applied forces, time, POSES) zero
 #pragma unroll
-    for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; }
+    for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.qc[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; }
     e.cube.pos[0] = e.cube.pos[1] = e.cube.pos[2] = 0.0f;
     e.cube.quat[0] = 1.0f; e.cube.quat[1] = e.cube.quat[2] = e.cube.quat[3] = 0.0f;
     e.ee[0] = e.ee[1] = e.ee[2] = 0.0f; e.wrist_z = 0.0f; e.cx[0] = e.cx[1] = e.cx[2] = 0.0f;
@@ -242,7 +244,7 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
 #pragma unroll 1
     for (int s = 0; s < p.frame_skip; s++) {
         cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
-        arm_substep<float>(e.q, e.v, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+        arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
         cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
     }
     e.nsub += p.frame_skip;

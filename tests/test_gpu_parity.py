@@ -316,3 +316,63 @@ def test_policy_kernel_vs_torch(kind):
     # the env step fills reward / done into the same rollout row
     ob, r, d, tr = sim.step(act_env, rollout_row=row)
     assert torch.equal(row[:, od + 6], r) and torch.equal(row[:, od + 7], d.float())
+
+
+def test_north_star_1000_steps():
+    """BASELINE.json north star: qpos/qvel within 1e-5 (relative to the joint-angle / velocity scale) of the fp64 CPU
+    physics over 1000 env steps = 16000 substeps on identical seeds.  Smooth bounded actions (a random walk), the
+    reference-faithful arm (friction loss + limits) and the constraint-free configuration."""
+    n, steps = 16, 1000
+    for flags in (ARM, FREE):
+        rs = np.random.RandomState(3)
+        sim = _sim(1, n, flags=flags, solver_iters=3, max_episode_steps=0, seed=2)
+        orc = [O.OracleEnv(1, flags=flags, iters=0, seed=2, env_id=i) for i in range(n)]
+        for e in orc:
+            e.e.max_episode_steps = 0
+        inj = rs.random_sample((n, 16)).astype(np.float32)
+        sim.reset(inject=torch.from_numpy(inj).cuda()); [e.reset(inject=inj[i]) for i, e in enumerate(orc)]
+        a = np.zeros((n, 6), np.float32); worst_q = worst_v = 0.0
+        for t in range(steps):
+            a = np.clip(a + rs.uniform(-0.2, 0.2, (n, 6)), -1, 1).astype(np.float32)
+            sim.step(torch.from_numpy(a).cuda())
+            for i, e in enumerate(orc):
+                e.step(a[i])
+            if t % 50 == 49 or t == steps - 1:
+                qpos, qvel = sim.get_state()
+                qo = np.stack([O.arr(e.d.qpos)[:6].copy() for e in orc]); vo = np.stack([O.arr(e.d.qvel)[:6].copy() for e in orc])
+                worst_q = max(worst_q, np.abs(qpos[:6].cpu().numpy().T - qo).max())
+                worst_v = max(worst_v, np.abs(qvel[:6].cpu().numpy().T - vo).max())
+        print(f"flags={flags}: 1000 steps, max |dq| = {worst_q:.2e} rad (scale pi), max |dqvel| = {worst_v:.2e} rad/s")
+        assert worst_q < 1e-5 * np.pi                       # 1e-5 relative to the angle scale (ranges span +-pi)
+        assert worst_v < 1e-5 * 40                          # velocities reach tens of rad/s under full-scale actions
+
+
+def test_rollout_collector_and_vecenv():
+    """The packaged fast path (collector) and the SB3 VecEnv adapter agree with stepping the handle by hand."""
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n, T = 256, 8
+    env = So100VecEnv("Env01-v1", n, flags=ARM, seed=9, max_episode_steps=5)
+    sd = RolloutCollector.random_policy_state(15, env.device, seed=1)
+    col = RolloutCollector(env, sd, T=T)
+    b = col.collect()
+    assert b["obs"].shape == (T, n, 15) and b["actions"].shape == (T, n, 6) and b["rewards"].shape == (T, n)
+    # replay by hand: same seeds, same policy noise stream (step counter), same actions
+    env2 = So100VecEnv("Env01-v1", n, flags=ARM, seed=9, max_episode_steps=5)
+    ob = env2.reset()
+    np.testing.assert_array_equal(ob, b["obs"][0].cpu().numpy())
+    n_done = 0
+    for t in range(T):
+        a = b["actions"][t].cpu().numpy()
+        ob, r, d, infos = env2.step(np.clip(a, -1, 1))
+        np.testing.assert_array_equal(r, b["rewards"][t].cpu().numpy())
+        np.testing.assert_array_equal(d.astype(np.float32), b["dones"][t].cpu().numpy())
+        if t + 1 < T:
+            np.testing.assert_array_equal(ob, b["obs"][t + 1].cpu().numpy())
+        for i in np.nonzero(d)[0]:
+            assert infos[i]["TimeLimit.truncated"] is True and infos[i]["terminal_observation"].shape == (15,)
+            assert infos[i]["episode"]["l"] == 5
+            n_done += 1
+    assert n_done == n                                       # every env hit its 5-step TimeLimit exactly once
+    assert len(infos) == n and env2.observation_space.shape == (15,) and env2.action_space.shape == (6,)
+    assert env2.env_is_wrapped(object) == [False] * n and env2.get_attr("num_envs", [0, 1]) == [n, n]
