@@ -5,9 +5,11 @@ One "step" = one vectorised env step of the rollout loop on every rank: policy f
 separate 2x64 tanh towers for pi and V, state-independent log-std Gaussian), action sampling + clipping, the fused
 HIP env step (reward -> ctrl -> 16 physics substeps -> obs -> TimeLimit -> auto-reset), and the write of
 obs/action/reward/done/value/log-prob into the on-device rollout buffer; every ROLLOUT_T steps the rollout chunk is
-gathered to the learner rank over RCCL (N > 1 only).  Default collector: two launches per step -- the fused policy
-kernel (so100_policy_forward) and the fused env step -- with no PyTorch op in the loop; `--policy torch` runs the
-same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
+gathered to the learner rank over RCCL (N > 1 only).  Default collector (`--policy persistent`): ONE launch per rollout chunk of 64 steps (so100_rollout: persistent
+workgroups, policy phase on all waves, physics phase on wave 0, env state in registers, weights in LDS).
+`--policy fused`: two launches per step (so100_policy_forward + so100_step), no PyTorch op in the loop.
+`--policy torch`: the same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).
+--steps / --warmup count vectorised env steps in every mode (they must be multiples of 64 for `persistent`).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
 GPU, contact disabled / no constraint solver (cube pinned), synthetic randomized-reset batches, random-init policy.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (so100_step_fused) with the algorithmic
@@ -90,7 +92,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_reference", "env02_reference", "env05_reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--policy", default="fused", choices=["fused", "torch"])
+    ap.add_argument("--policy", default="persistent", choices=["persistent", "fused", "torch"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
@@ -119,7 +121,7 @@ def main():
     noise = torch.empty(n, 6, device=dev)
 
     act = torch.zeros(n, 6, device=dev)
-    if args.policy == "fused":
+    if args.policy in ("fused", "persistent"):
         sim.set_policy({"pi_w0": pol.pi[0][0].t().contiguous(), "pi_b0": pol.pi[0][1], "pi_w1": pol.pi[1][0].t().contiguous(), "pi_b1": pol.pi[1][1],
                         "mu_w": pol.mu[0].t().contiguous(), "mu_b": pol.mu[1], "log_std": pol.log_std,
                         "vf_w0": pol.vf[0][0].t().contiguous(), "vf_b0": pol.vf[0][1], "vf_w1": pol.vf[1][0].t().contiguous(), "vf_b1": pol.vf[1][1],
@@ -128,7 +130,10 @@ def main():
 
     def vec_step(t):
         row = chunk[t % T]
-        if args.policy == "fused":
+        if args.policy == "persistent":
+            if (t + 1) % T == 0:                                               # one launch per rollout chunk of T steps
+                sim.rollout(chunk, counter[0]); counter[0] += T
+        elif args.policy == "fused":
             sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
             sim.step(act, rollout_row=row)                                     # reward | done -> row
             counter[0] += 1

@@ -110,6 +110,24 @@ typedef struct {
 int  so100_policy_forward(so100_sim* sim, const so100_policy_weights* w, const so100_policy_io* io,
                           uint32_t step_counter, void* hip_stream);
 
+/* T vectorised steps of {policy forward, sample, clip, env step, rollout-buffer write} in ONE launch (persistent
+ * workgroups: env state stays in registers, weights in LDS; csrc/so100_rollout.hpp).  Equivalent, step for step, to
+ * calling so100_policy_forward(step_counter0 + t) + so100_step T times.  ref: the loop body of stable_baselines3
+ * OnPolicyAlgorithm.collect_rollouts driven from main.py:234-238. */
+typedef struct {
+    float*   rollout_dev;          /* [T][N][obs_dim+10] rows: obs | raw action(6) | reward | done | value | logp   */
+    float*   obs_dev;              /* [N][obs_dim] in: current observation; out: observation after the last step     */
+    float*   rew_dev;              /* [N] last step's reward                                                        */
+    uint8_t* done_dev;             /* [N] last step's done                                                          */
+    uint8_t* trunc_dev;            /* [N] last step's TimeLimit.truncated                                           */
+    float*   terminal_obs_dev;     /* [N][obs_dim] written where an episode ended (latest); nullable                 */
+    float*   ep_return_dev;        /* [N] nullable                                                                  */
+    int32_t* ep_length_dev;        /* [N] nullable                                                                  */
+} so100_rollout_io;
+
+int  so100_rollout(so100_sim* sim, const so100_policy_weights* w, const so100_rollout_io* io, int32_t T,
+                   uint32_t step_counter0, void* hip_stream);
+
 int  so100_abi_version(void);
 int  so100_obs_dim(int32_t env_kind);                     /* ref: env_base_01.py:63-75 (15), env_base_02.py:56-69 (8) */
 int  so100_num_state_fields(void);                        /* rows of the [field][N] state matrix */

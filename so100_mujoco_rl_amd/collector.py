@@ -15,12 +15,13 @@ from .rollout import RolloutChunk, gather_rollout
 
 
 class RolloutCollector:
-    def __init__(self, vec_env, state_dict, T=64):
+    def __init__(self, vec_env, state_dict, T=64, persistent=True):
         self.env = vec_env; self.sim = vec_env.sim
         self.T = T
         self.chunk = RolloutChunk(T, self.sim.n, self.sim.obs_dim, self.sim.device)
         self.act = torch.zeros(self.sim.n, 6, device=self.sim.device)
         self.counter = 0
+        self.persistent = persistent            # one launch per chunk (so100_rollout) vs two launches per step
         self.load_policy(state_dict)
         self._started = False
 
@@ -54,11 +55,15 @@ class RolloutCollector:
         assert T <= self.T
         if not self._started:
             self.env.reset_tensor(); self._started = True
-        for t in range(T):
-            row = self.chunk.buf[t]
-            self.sim.policy_forward(self.sim.obs, self.act, self.counter, rollout_row=row)
-            self.sim.step(self.act, rollout_row=row)
-            self.counter += 1
+        if self.persistent:
+            self.sim.rollout(self.chunk.buf[:T], self.counter)
+            self.counter += T
+        else:
+            for t in range(T):
+                row = self.chunk.buf[t]
+                self.sim.policy_forward(self.sim.obs, self.act, self.counter, rollout_row=row)
+                self.sim.step(self.act, rollout_row=row)
+                self.counter += 1
         buf = self.chunk.buf[:T]
         if gather_dst is not None:
             buf = gather_rollout(buf.contiguous(), dst=gather_dst)

@@ -36,6 +36,8 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f*trcp(e + 1.0f);
 }
 
+__device__ __forceinline__ void policy_noise(uint32_t env_gid, uint32_t step_counter, uint32_t seed_lo, uint32_t seed_hi, float eps[8]);
+
 template <int OD, int NW>
 __global__ void __launch_bounds__(64*NW) so100_policy_forward_kernel(int n, PolicyWeights w, PolicyIO io, uint32_t seed_lo, uint32_t seed_hi,
                                                             uint32_t env_id_offset, uint32_t step_counter) {
@@ -129,19 +131,7 @@ __global__ void __launch_bounds__(64*NW) so100_policy_forward_kernel(int n, Poli
 #pragma unroll
             for (int a = 0; a < 6; a++) eps[a] = eps_in[a];
         } else {
-#pragma unroll
-            for (int b = 0; b < 2; b++) {
-                uint32_t r[4];
-                philox4x32(env_id_offset + (uint32_t)env, step_counter, 16u + (uint32_t)b, 0x504F4Cu, seed_lo, seed_hi, r);
-#pragma unroll
-                for (int i = 0; i < 2; i++) {                                  // Box-Muller on (0,1] x [0,1)
-                    const float u1 = ((float)(r[2*i] >> 8) + 1.0f) * (1.0f/16777216.0f);
-                    const float u2 = (float)(r[2*i + 1] >> 8) * (1.0f/16777216.0f);
-                    const float rad = __builtin_sqrtf(-2.0f*__builtin_logf(u1));
-                    float s, c; tsincos<float>(6.283185307179586f*u2 - 3.141592653589793f, s, c);
-                    eps[4*b + 2*i] = rad*c; eps[4*b + 2*i + 1] = rad*s;
-                }
-            }
+            policy_noise(env_id_offset + (uint32_t)env, step_counter, seed_lo, seed_hi, eps);
         }
         float lp = 0.0f;
         if (live) {
@@ -168,6 +158,25 @@ __global__ void __launch_bounds__(64*NW) so100_policy_forward_kernel(int n, Poli
         if (live) {
             if (io.value) io.value[env] = v;
             if (io.rollout_row) io.rollout_row[(size_t)env*(OD + 10) + OD + 8] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Sampling head shared by the stand-alone policy kernel's wave 0 and the persistent rollout kernel
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void policy_noise(uint32_t env_gid, uint32_t step_counter, uint32_t seed_lo, uint32_t seed_hi, float eps[8]) {
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        uint32_t r[4];
+        philox4x32(env_gid, step_counter, 16u + (uint32_t)b, 0x504F4Cu, seed_lo, seed_hi, r);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {                                  // Box-Muller on (0,1] x [0,1)
+            const float u1 = ((float)(r[2*i] >> 8) + 1.0f) * (1.0f/16777216.0f);
+            const float u2 = (float)(r[2*i + 1] >> 8) * (1.0f/16777216.0f);
+            const float rad = __builtin_sqrtf(-2.0f*__builtin_logf(u1));
+            float sn, cs; tsincos<float>(6.283185307179586f*u2 - 3.141592653589793f, sn, cs);
+            eps[4*b + 2*i] = rad*cs; eps[4*b + 2*i + 1] = rad*sn;
         }
     }
 }

@@ -1,0 +1,182 @@
+// so100_rollout.hpp -- persistent rollout kernel: T vectorised steps of {policy forward, sample, env step} in ONE launch.
+//
+// One workgroup = NW waves = 64 envs.  Each step has two phases:
+//   policy phase  (all 4 waves): the two hidden layers of both towers on the matrix cores (fp32 MFMA, weight
+//                 fragments resident in VGPRs for the whole launch, activations through LDS); the heads on the VALU:
+//                 wave 0 ends with the action of env = lane in registers.
+//   physics phase (wave 0 only):  the same fused env step as so100_step_fused (reward -> ctrl -> 16 substeps -> obs ->
+//                 TimeLimit -> auto-reset); the other waves sleep at the workgroup barrier.
+// The env state lives in wave 0's registers across all T steps (loaded once, stored once per launch), the
+// observation goes to the next policy phase through LDS, and the only per-step HBM traffic is the rollout-buffer row
+// (obs | action | reward | done | value | logp = (obs_dim+10) words per env).  Compared with one policy launch + one
+// env launch per step this removes 2T-1 kernel boundaries, the per-step state round trip and the per-launch
+// first-touch latencies of the weights.
+#pragma once
+#include "so100_policy.hpp"
+
+namespace so100 {
+
+struct RolloutArgs {
+    float* buf;                  // [T][N][OD+10]
+    int32_t T;
+    uint32_t step_counter0;      // policy-noise Philox counter of the first step
+    const float* obs_in;         // [N][OD] current observation (reset or previous launch)
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Policy hidden layers on the matrix cores: per tower and layer, H[64 envs][64 units] = tanh(X[64][K] W^T + b) is a genuine
+// contraction (K = 16 / 64).  v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain, so results are bit-compatible
+// with the VALU policy kernel).  4 waves = one per SIMD: wave w owns tower w>>1, env rows [32(w&1), +32) and both 32-unit
+// column tiles; its B fragments (weights) stay in VGPRs for the whole launch, A fragments (activations) come from LDS in
+// [env][unit] layout with a 65-float row stride (conflict-free for the A read, the D write and the per-lane head read).
+template <int KIND, int FL, int NW>
+__global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float* __restrict__ state, const float* start_tab,
+                                                             float* obs_out, float* rew_out, uint8_t* done_out, uint8_t* trunc_out,
+                                                             float* tobs_out, float* ep_ret_out, int32_t* ep_len_out,
+                                                             PolicyWeights w, RolloutArgs ra) {
+    static_assert(NW == 4, "one wave per SIMD: (tower, row tile) per wave");
+    constexpr int OD = obs_dim<KIND>();
+    constexpr int ODP = (OD + 3) & ~3;                            // K of layer 1, padded with zero weights
+    constexpr int LD = 65;                                        // LDS row stride of the [env][unit] activation images
+    __shared__ __attribute__((aligned(16))) float hd[6*64 + 64 + 16];   // mu_w | v_w | mu_b(6) log_std(6) v_b(1)
+    __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
+    __shared__ float h1t[2][64][LD];
+    __shared__ float h2t[2][64][LD];
+    if (FL >= 0) p.flags = (unsigned)FL;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env = blockIdx.x*64 + lane;
+    const bool live = env < p.n;
+    const int tower = wave >> 1, rt = wave & 1;
+    const int lj = lane & 31, lh = lane >> 5;
+    // ---- once per launch: weight fragments -> registers, head weights -> LDS, env state -> registers, obs -> LDS
+    const float* W1 = tower ? w.vf_w0 : w.pi_w0; const float* W2 = tower ? w.vf_w1 : w.pi_w1;
+    const float* Bi1 = tower ? w.vf_b0 : w.pi_b0; const float* Bi2 = tower ? w.vf_b1 : w.pi_b1;
+    float bw1[2][ODP/2], bw2[2][32], b1v[2], b2v[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+        const int unit = 32*ct + lj;
+        b1v[ct] = Bi1[unit]; b2v[ct] = Bi2[unit];
+#pragma unroll
+        for (int s2 = 0; s2 < ODP/2; s2++) { const int k = 2*s2 + lh; bw1[ct][s2] = k < OD ? W1[unit*OD + k] : 0.0f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) bw2[ct][s2] = W2[unit*64 + 2*s2 + lh];
+    }
+    if (wave == NW - 1) {
+        for (int i = lane; i < 6*64; i += 64) hd[i] = w.mu_w[i];
+        hd[6*64 + lane] = w.v_w[lane];
+        if (lane < 6) { hd[7*64 + lane] = w.mu_b[lane]; hd[7*64 + 6 + lane] = w.log_std[lane]; }
+        if (lane == 0) hd[7*64 + 12] = w.v_b[0];
+    }
+    EnvState e;
+    if (wave == 0) {
+        if (live) load_env_state<KIND>(state, p.n, env, e); else e = EnvState{};
+#pragma unroll
+        for (int k = 0; k < ODP; k++) oxt[lane][k] = (live && k < OD) ? ra.obs_in[(size_t)env*OD + k] : 0.0f;
+    }
+    __syncthreads();
+    StepResult last{}; float last_obs[OD];
+#pragma unroll 1
+    for (int t = 0; t < ra.T; t++) {
+        // ---- layer 1: K = ODP
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = b1v[0]; acc1[r] = b1v[1]; }
+#pragma unroll
+            for (int s2 = 0; s2 < ODP/2; s2++) {
+                const float a = oxt[32*rt + lj][2*s2 + lh];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw1[0][s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw1[1][s2], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32*rt + (r & 3) + 8*(r >> 2) + 4*lh;
+                h1t[tower][row][lj] = fast_tanh(acc0[r]); h1t[tower][row][32 + lj] = fast_tanh(acc1[r]);
+            }
+        }
+        __syncthreads();
+        // ---- layer 2: K = 64
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = b2v[0]; acc1[r] = b2v[1]; }
+#pragma unroll
+            for (int s2 = 0; s2 < 32; s2++) {
+                const float a = h1t[tower][32*rt + lj][2*s2 + lh];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[0][s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[1][s2], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32*rt + (r & 3) + 8*(r >> 2) + 4*lh;
+                h2t[tower][row][lj] = fast_tanh(acc0[r]); h2t[tower][row][32 + lj] = fast_tanh(acc1[r]);
+            }
+        }
+        __syncthreads();
+        float* row = ra.buf + ((size_t)t*p.n + (size_t)env)*(OD + 10);
+        if (wave == 0) {
+            // ---- head (VALU, lane = env): mean -> sample -> clip; then the physics phase
+            float mean[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) mean[a] = hd[7*64 + a];
+#pragma unroll 4
+            for (int k = 0; k < 64; k += 4) {
+                const float x0 = h2t[0][lane][k], x1 = h2t[0][lane][k+1], x2 = h2t[0][lane][k+2], x3 = h2t[0][lane][k+3];
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(&hd[a*64 + k]);
+                    mean[a] = __builtin_fmaf(m4.x, x0, mean[a]); mean[a] = __builtin_fmaf(m4.y, x1, mean[a]);
+                    mean[a] = __builtin_fmaf(m4.z, x2, mean[a]); mean[a] = __builtin_fmaf(m4.w, x3, mean[a]);
+                }
+            }
+            float eps[8];
+            policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)t, p.seed_lo, p.seed_hi, eps);
+            float act[6], lp = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const float ls = hd[7*64 + 6 + a];
+                const float raw = __builtin_fmaf(__builtin_expf(ls), eps[a], mean[a]);
+                lp += -0.5f*eps[a]*eps[a] - ls - 0.9189385332046727f;
+                act[a] = tclamp(raw, -1.0f, 1.0f);
+                if (live) row[OD + a] = raw;
+            }
+            if (live) {
+#pragma unroll
+                for (int k = 0; k < OD; k++) row[k] = oxt[lane][k];
+                row[OD + 9] = lp;
+                float obs[OD], tobs[OD];
+                const StepResult r = env_step_vec<KIND>(e, act, p, p.env_id_offset + (uint32_t)env, nullptr, start_tab, obs, tobs);
+                row[OD + 6] = r.reward; row[OD + 7] = r.done ? 1.0f : 0.0f;
+#pragma unroll
+                for (int k = 0; k < OD; k++) { oxt[lane][k] = obs[k]; last_obs[k] = obs[k]; }
+                last = r;
+                if (r.done) {
+                    if (tobs_out) {
+#pragma unroll
+                        for (int k = 0; k < OD; k++) tobs_out[(size_t)env*OD + k] = tobs[k];
+                    }
+                    if (ep_ret_out) ep_ret_out[env] = r.ep_return;
+                    if (ep_len_out) ep_len_out[env] = r.ep_length;
+                }
+            }
+        } else if (wave == 2) {
+            float v = hd[7*64 + 12];
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) v = __builtin_fmaf(hd[6*64 + k], h2t[1][lane][k], v);
+            if (live) row[OD + 8] = v;
+        }
+        __syncthreads();
+    }
+    if (wave == 0 && live) {
+        store_env_state<KIND>(state, p.n, env, e);
+        if (ra.T > 0) {
+#pragma unroll
+            for (int k = 0; k < OD; k++) obs_out[(size_t)env*OD + k] = last_obs[k];
+            rew_out[env] = last.reward; done_out[env] = last.done ? 1 : 0; trunc_out[env] = last.trunc_only ? 1 : 0;
+        }
+    }
+}
+
+}  // namespace so100

@@ -16,6 +16,28 @@
 #include "so100_task.hpp"
 #include "so100_policy.hpp"
 
+namespace so100 {
+// ---- SoA load / store of one env ----------------------------------------------------------------------
+template <int KIND> __device__ __forceinline__ void load_env_state(const float* __restrict__ S, int n, int env, EnvState& e) {
+#define X(name, member, kind, group) \
+    if constexpr (uses_group<KIND>(group)) { const float w_ = S[(size_t)SF_##name*n + env]; \
+        if constexpr (#kind[0] == 'i') e.member = __float_as_int(w_); else e.member = w_; }
+    SO100_STATE_FIELDS(X)
+#undef X
+}
+template <typename M> __device__ __forceinline__ float as_word(M v) {
+    if constexpr (sizeof(M) == 4 && !__is_floating_point(M)) return __int_as_float((int)v); else return (float)v;
+}
+template <int KIND> __device__ __forceinline__ void store_env_state(float* __restrict__ S, int n, int env, const EnvState& e) {
+#define X(name, member, kind, group) \
+    if constexpr (uses_group<KIND>(group)) S[(size_t)SF_##name*n + env] = as_word(e.member);
+    SO100_STATE_FIELDS(X)
+#undef X
+}
+
+}  // namespace so100
+#include "so100_rollout.hpp"
+
 namespace {
 
 using namespace so100;
@@ -29,24 +51,6 @@ int fail(int code, const char* fmt, const char* a = "", long b = 0) {
     return fail(code, "%s (HIP error %ld)", hipGetErrorString(e_), (long)e_); } while (0)
 
 constexpr int WG = 64;      // one wavefront per workgroup
-
-// ---- SoA load / store of one env ----------------------------------------------------------------------
-template <int KIND> __device__ __forceinline__ void load_env(const float* __restrict__ S, int n, int env, EnvState& e) {
-#define X(name, member, kind, group) \
-    if constexpr (uses_group<KIND>(group)) { const float w_ = S[(size_t)SF_##name*n + env]; \
-        if constexpr (#kind[0] == 'i') e.member = __float_as_int(w_); else e.member = w_; }
-    SO100_STATE_FIELDS(X)
-#undef X
-}
-template <typename M> __device__ __forceinline__ float as_word(M v) {
-    if constexpr (sizeof(M) == 4 && !__is_floating_point(M)) return __int_as_float((int)v); else return (float)v;
-}
-template <int KIND> __device__ __forceinline__ void store_env(float* __restrict__ S, int n, int env, const EnvState& e) {
-#define X(name, member, kind, group) \
-    if constexpr (uses_group<KIND>(group)) S[(size_t)SF_##name*n + env] = as_word(e.member);
-    SO100_STATE_FIELDS(X)
-#undef X
-}
 
 struct StepPtrs {
     float* state; const float* start_tab;
@@ -65,7 +69,7 @@ __global__ void __launch_bounds__(WG) so100_step_fused(SimParams p, StepPtrs io)
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
     EnvState e;
-    load_env<KIND>(io.state, p.n, env, e);
+    load_env_state<KIND>(io.state, p.n, env, e);
     float a[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) a[i] = io.act[(size_t)env*6 + i];
@@ -73,7 +77,7 @@ __global__ void __launch_bounds__(WG) so100_step_fused(SimParams p, StepPtrs io)
     float obs[OD], tobs[OD];
     const float* inj = io.inject ? io.inject + (size_t)env*SO100_NINJECT : nullptr;
     const StepResult r = env_step_vec<KIND>(e, a, p, p.env_id_offset + (uint32_t)env, inj, io.start_tab, obs, tobs);
-    store_env<KIND>(io.state, p.n, env, e);
+    store_env_state<KIND>(io.state, p.n, env, e);
 #pragma unroll
     for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];
     io.rew[env] = r.reward;
@@ -101,7 +105,7 @@ __global__ void __launch_bounds__(WG) so100_reset_masked(SimParams p, float* sta
     if (env >= p.n) return;
     if (mask && !mask[env]) return;
     EnvState e;
-    load_env<KIND>(state, p.n, env, e);
+    load_env_state<KIND>(state, p.n, env, e);
     float u[8];
     const float* inj = inject ? inject + (size_t)env*SO100_NINJECT : nullptr;
     draw8(p, p.env_id_offset + (uint32_t)env, (uint32_t)e.rngc, 1, inj, u);
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(WG) so100_reset_masked(SimParams p, float* sta
     constexpr int OD = obs_dim<KIND>();
     float obs[OD];
     env_reset<KIND>(e, u, start_tab, obs);
-    store_env<KIND>(state, p.n, env, e);
+    store_env_state<KIND>(state, p.n, env, e);
     if (obs_out) {
 #pragma unroll
         for (int i = 0; i < OD; i++) obs_out[(size_t)env*OD + i] = obs[i];
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(WG) so100_init_state(int n, float* state) {
     for (int f = 0; f < SF_COUNT; f++) state[(size_t)f*n + env] = 0.0f;
     EnvState e;
     env_init<KIND>(e);
-    store_env<KIND>(state, n, env, e);
+    store_env_state<KIND>(state, n, env, e);
 }
 
 const char* const kFieldNames[] = {
@@ -286,6 +290,33 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
     if (s->cfg.env_kind <= 2) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
     else                      { if (nw == 4) SO100_LAUNCH_POLICY(8, 4);  else if (nw == 8) SO100_LAUNCH_POLICY(8, 8);  else SO100_LAUNCH_POLICY(8, 16); }
 #undef SO100_LAUNCH_POLICY
+    HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
+    return 0;
+}
+
+int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollout_io* io, int32_t T, uint32_t step_counter0, void* stream) {
+    if (!s || !w || !io) return fail(SO100_E_INVALID, "so100_rollout: null argument%s");
+    if (T < 1) return fail(SO100_E_INVALID, "so100_rollout: T must be >= 1%s");
+    if (!io->rollout_dev || !io->obs_dev || !io->rew_dev || !io->done_dev || !io->trunc_dev)
+        return fail(SO100_E_INVALID, "so100_rollout: rollout/obs/rew/done/trunc pointers are required%s");
+    const float* const* wp = reinterpret_cast<const float* const*>(w);
+    for (int i = 0; i < 13; i++) if (!wp[i]) return fail(SO100_E_INVALID, "so100_rollout: null weight pointer%s");
+    DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_rollout: cannot select the device%s");
+    PolicyWeights pw; memcpy(&pw, w, sizeof pw);
+    RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev;
+    const dim3 grid((unsigned)((s->prm.n + 63)/64));
+    hipStream_t st = (hipStream_t)stream;
+#define SO100_RL(KIND, FLV, NW) hipLaunchKernelGGL((so100_rollout_fused<KIND, FLV, NW>), grid, dim3(64*NW), 0, st, s->prm, s->state, s->start_tab, \
+        io->obs_dev, io->rew_dev, io->done_dev, io->trunc_dev, io->terminal_obs_dev, io->ep_return_dev, io->ep_length_dev, pw, ra)
+#define SO100_RL_FL(KIND, NW) do { if (s->prm.flags == SO100_F_CUBE_PINNED) SO100_RL(KIND, SO100_F_CUBE_PINNED, NW); \
+        else if (s->prm.flags == SO100_F_REFERENCE) SO100_RL(KIND, SO100_F_REFERENCE, NW); else SO100_RL(KIND, -1, NW); } while (0)
+#define SO100_RL_KIND(NW) switch (s->cfg.env_kind) { case 1: SO100_RL_FL(1, NW); break; case 2: SO100_RL_FL(2, NW); break; \
+        case 3: SO100_RL_FL(3, NW); break; case 4: SO100_RL_FL(4, NW); break; default: SO100_RL_FL(5, NW); }
+    SO100_RL_KIND(4)
+#undef SO100_RL_KIND
+#undef SO100_RL_FL
+#undef SO100_RL
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }

@@ -50,13 +50,18 @@ class PolicyWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in POLICY_TENSORS]
 
 
+class RolloutIO(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("rollout_dev", "obs_dev", "rew_dev", "done_dev", "trunc_dev", "terminal_obs_dev",
+                                          "ep_return_dev", "ep_length_dev")]
+
+
 class PolicyIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs_dev", "noise_dev", "act_env_dev", "act_raw_dev", "value_dev", "logp_dev", "rollout_row_dev")]
 
 
 EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_create",
            "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
-           "so100_set_field", "so100_last_error", "so100_policy_forward"]
+           "so100_set_field", "so100_last_error", "so100_policy_forward", "so100_rollout"]
 
 
 def build(verbose=False):
@@ -88,6 +93,7 @@ def load():
         L.so100_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_step.argtypes = [C.c_void_p, C.POINTER(StepIO), C.c_void_p]
         L.so100_policy_forward.argtypes = [C.c_void_p, C.POINTER(PolicyWeights), C.POINTER(PolicyIO), C.c_uint32, C.c_void_p]
+        L.so100_rollout.argtypes = [C.c_void_p, C.POINTER(PolicyWeights), C.POINTER(RolloutIO), C.c_int32, C.c_uint32, C.c_void_p]
         L.so100_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -193,6 +199,14 @@ class So100Sim:
         io.logp_dev = _ptr(logp, torch.float32, (self.n,), self.device)
         io.rollout_row_dev = _ptr(rollout_row, torch.float32, (self.n, self.obs_dim + 10), self.device)
         _check(self.L.so100_policy_forward(self.h, C.byref(self._pw), C.byref(io), int(step_counter) & 0xFFFFFFFF, self._stream()), "so100_policy_forward")
+
+    def rollout(self, rollout_buf, step_counter0):
+        """T = rollout_buf.shape[0] steps of {policy, sample, env step, buffer write} in one launch (persistent kernel).
+        rollout_buf: float32 [T, N, obs_dim+10].  Uses / updates the handle's obs, rew, done, ... tensors."""
+        T = rollout_buf.shape[0]
+        io = RolloutIO(_ptr(rollout_buf, torch.float32, (T, self.n, self.obs_dim + 10), self.device), self.obs.data_ptr(), self.rew.data_ptr(),
+                       self.done.data_ptr(), self.trunc.data_ptr(), self.terminal_obs.data_ptr(), self.ep_return.data_ptr(), self.ep_length.data_ptr())
+        _check(self.L.so100_rollout(self.h, C.byref(self._pw), C.byref(io), T, int(step_counter0) & 0xFFFFFFFF, self._stream()), "so100_rollout")
 
     def get_state(self):
         qpos = torch.empty(13, self.n, dtype=torch.float32, device=self.device)

@@ -376,3 +376,27 @@ def test_rollout_collector_and_vecenv():
     assert n_done == n                                       # every env hit its 5-step TimeLimit exactly once
     assert len(infos) == n and env2.observation_space.shape == (15,) and env2.action_space.shape == (6,)
     assert env2.env_is_wrapped(object) == [False] * n and env2.get_attr("num_envs", [0, 1]) == [n, n]
+
+
+@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, REF), (2, REF), (5, REF), (1, ARM)])
+def test_persistent_rollout_equals_stepwise(kind, flags):
+    """so100_rollout (one launch for T steps) == T x (so100_policy_forward + so100_step), buffer row by row."""
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n, T = 200, 12                                           # tail workgroup partially filled; TimeLimit hits inside the chunk
+    outs = []
+    for persistent in (True, False):
+        env = So100VecEnv(kind, n, flags=flags, seed=4, max_episode_steps=7)
+        sd = RolloutCollector.random_policy_state(env.sim.obs_dim, env.device, seed=2)
+        sd["log_std"] = sd["log_std"] - 0.5
+        col = RolloutCollector(env, sd, T=T, persistent=persistent)
+        b1 = {k: v.clone() for k, v in col.collect().items()}
+        b2 = {k: v.clone() for k, v in col.collect(5).items()}          # a second, shorter chunk continues the episode
+        q, v = env.sim.get_state()
+        outs.append((b1, b2, q, v, env.sim.terminal_obs.clone(), env.sim.ep_length.clone()))
+    (a1, a2, aq, av, at, al), (s1, s2, sq, sv, st_, sl) = outs
+    for a, s in ((a1, s1), (a2, s2)):
+        for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
+            assert torch.allclose(a[k], s[k], rtol=0, atol=1e-6), k
+    assert torch.allclose(aq, sq, atol=1e-6) and torch.allclose(av, sv, atol=1e-5)
+    assert a1["dones"].sum() > 0 and torch.equal(al, sl) and torch.allclose(at, st_, atol=1e-6)
