@@ -9,7 +9,7 @@ gathered to the learner rank over RCCL (N > 1 only).  Default collector (`--poli
 workgroups, policy phase on all waves, physics phase on wave 0, env state in registers, weights in LDS).
 `--policy fused`: two launches per step (so100_policy_forward + so100_step), no PyTorch op in the loop.
 `--policy torch`: the same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).
---steps / --warmup count vectorised env steps in every mode (they must be multiples of 64 for `persistent`).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
+--steps / --warmup count vectorised env steps in every mode (a trailing partial chunk is one shorter launch).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
 GPU, contact disabled / no constraint solver (cube pinned), synthetic randomized-reset batches, random-init policy.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (so100_step_fused) with the algorithmic
@@ -116,8 +116,11 @@ def main():
     pol = MlpPolicy(sim.obs_dim, 6, dev, seed=0)
     T = ROLLOUT_T
     k = sim.obs_dim + 6 + 4                                  # obs, action, reward, done, value, logp
-    chunk = torch.zeros(T, n, k, device=dev)
+    # two chunk buffers: while chunk i is gathered to the learner over RCCL (async, on the collective's own stream),
+    # the next rollout chunk is already being produced into buffer 1-i
+    chunks = [torch.zeros(T, n, k, device=dev) for _ in range(2 if world > 1 else 1)]
     gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    pending = [None, None]
     noise = torch.empty(n, 6, device=dev)
 
     act = torch.zeros(n, 6, device=dev)
@@ -128,37 +131,49 @@ def main():
                         "v_w": pol.v[0].t().contiguous(), "v_b": pol.v[1]})
     counter = [0]
 
-    def vec_step(t):
-        row = chunk[t % T]
-        if args.policy == "persistent":
-            if (t + 1) % T == 0:                                               # one launch per rollout chunk of T steps
-                sim.rollout(chunk, counter[0]); counter[0] += T
-        elif args.policy == "fused":
-            sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
-            sim.step(act, rollout_row=row)                                     # reward | done -> row
-            counter[0] += 1
-        else:
-            noise.normal_(generator=g)
-            a, value, logp = pol.forward(sim.obs, noise)
-            row[:, :sim.obs_dim] = sim.obs
-            row[:, sim.obs_dim:sim.obs_dim + 6] = a
-            a = a.clamp_(-1.0, 1.0)
-            ob, rew, done, trunc = sim.step(a)
-            row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
-        if world > 1 and (t + 1) % T == 0:
-            dist.gather(chunk, gathered, dst=0)              # RCCL: rollout chunk -> learner rank
+    def run(nsteps):
+        """exactly nsteps vectorised env steps, in rollout chunks of at most T steps"""
+        ci = 0
+        for c0 in range(0, nsteps, T):
+            Tc = min(T, nsteps - c0)
+            ci ^= (len(chunks) - 1)
+            if pending[ci] is not None:                      # buffer about to be overwritten: its gather must be done
+                pending[ci].wait(); pending[ci] = None
+            chunk = chunks[ci][:Tc]
+            if args.policy == "persistent":
+                sim.rollout(chunk, counter[0]); counter[0] += Tc               # ONE launch for Tc steps
+            else:
+                for t in range(Tc):
+                    row = chunk[t]
+                    if args.policy == "fused":
+                        sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
+                        sim.step(act, rollout_row=row)                                     # reward | done -> row
+                        counter[0] += 1
+                    else:
+                        noise.normal_(generator=g)
+                        a, value, logp = pol.forward(sim.obs, noise)
+                        row[:, :sim.obs_dim] = sim.obs
+                        row[:, sim.obs_dim:sim.obs_dim + 6] = a
+                        a = a.clamp_(-1.0, 1.0)
+                        ob, rew, done, trunc = sim.step(a)
+                        row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
+            if world > 1:
+                # RCCL: rollout chunk -> learner rank.  The collective is ordered after the producing kernel on this
+                # stream and runs on its own stream; nothing waits for it until this buffer is reused (two chunks later).
+                pending[ci] = dist.gather(chunk, [gb[:Tc] for gb in gathered] if gathered is not None else None, dst=0, async_op=True)
 
     def sync():
+        for i, wk in enumerate(pending):
+            if wk is not None:
+                wk.wait(); pending[i] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for t in range(args.warmup):
-        vec_step(t)
+    run(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for t in range(args.steps):
-        vec_step(t)
+    run(args.steps)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:

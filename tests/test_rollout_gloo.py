@@ -39,6 +39,25 @@ def _worker(rank, world, port, n_local, T, q):
                         torch.from_numpy((term | trunc).astype(np.float32)), torch.full((n_local,), float(rank)), torch.zeros(n_local))
             obs = o2.copy()
         full = gather_rollout(chunk.buf, dst=0)
+        # bench.py's pattern: two chunk buffers, async gather of buffer i while buffer 1-i is being produced
+        bufs = [torch.zeros(T, n_local, 25), torch.zeros(T, n_local, 25)]
+        recv = [torch.zeros(T, n_local, 25) for _ in range(world)] if rank == 0 else None
+        pending = [None, None]; seen = []
+        ci = 0
+        for c in range(5):
+            Tc = T if c < 4 else 2                           # trailing partial chunk
+            ci ^= 1
+            if pending[ci] is not None:
+                pending[ci].wait(); pending[ci] = None
+                if rank == 0: seen.append([float(r[0, 0, 0]) for r in recv])
+            bufs[ci][:Tc] = 100.0 * c + rank
+            pending[ci] = dist.gather(bufs[ci][:Tc], [r[:Tc] for r in recv] if rank == 0 else None, dst=0, async_op=True)
+        for i, wk in enumerate(pending):
+            if wk is not None:
+                wk.wait()
+        if rank == 0:
+            assert [float(r[0, 0, 0]) for r in recv] == [400.0 + k for k in range(world)]       # last (partial) chunk, rank order
+            assert float(recv[1][2, 0, 0]) == 301.0                                            # rows beyond Tc keep chunk 3
         w = torch.full((4,), float(rank + 1)); broadcast_policy([w], src=0)
         assert torch.all(w == 1.0)
         if rank == 0:
