@@ -179,33 +179,42 @@ def main():
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
 
-    # dominant kernel alone: HIP events on the launch stream around back-to-back so100_step launches
-    act = torch.rand(n, 6, device=dev) * 2 - 1
-    act = act.contiguous()
-    for _ in range(20):
-        sim.step(act)
+    # dominant kernel alone: HIP events on the launch stream (torch's current stream, where the C ABI enqueues) around
+    # back-to-back launches.  persistent mode: so100_rollout_fused, one launch = T x N env-steps; otherwise so100_step_fused.
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    reps = 200
-    torch.cuda.synchronize(dev)
-    e0.record()
-    for _ in range(reps):
-        sim.step(act)
-    e1.record(); torch.cuda.synchronize(dev)
+    if args.policy == "persistent":
+        kernel_name, units, reps = "so100_rollout_fused", n * T, 12
+        for _ in range(2):
+            sim.rollout(chunks[0], counter[0]); counter[0] += T
+        torch.cuda.synchronize(dev); e0.record()
+        for _ in range(reps):
+            sim.rollout(chunks[0], counter[0]); counter[0] += T
+        e1.record(); torch.cuda.synchronize(dev)
+    else:
+        kernel_name, units, reps = "so100_step_fused", n, 200
+        a2 = (torch.rand(n, 6, device=dev) * 2 - 1).contiguous()
+        for _ in range(20):
+            sim.step(a2)
+        torch.cuda.synchronize(dev); e0.record()
+        for _ in range(reps):
+            sim.step(a2)
+        e1.record(); torch.cuda.synchronize(dev)
     kern_ms = e0.elapsed_time(e1) / reps
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be collected from inside this process; the
     # committed PMC pass (profiles/r01_c_pmc_summary.json, same workload / batch size) is quoted when it matches.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_pmc_summary.json" if args.policy == "persistent" else "r01_c_pmc_summary.json")))
         if args.workload == "env01_free" and n == 4096:
-            traffic = [v for k, v in pmc["kernels"].items() if "step_fused" in k][0]["hbm_traffic_bytes_per_launch"]
+            key = "rollout_fused" if args.policy == "persistent" else "step_fused"
+            traffic = [v for k, v in pmc["kernels"].items() if key in k][0]["hbm_traffic_bytes_per_launch"]
     except Exception:
         traffic = None
 
     if rank == 0:
         value = world * n * args.steps / dt
-        achieved = BYTES_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e9
+        achieved = BYTES_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env steps/sec at 4096 envs/GPU, Env01 PPO rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -215,10 +224,10 @@ def main():
                                    + ", SB3-MlpPolicy-shaped rollout (" + args.policy + " policy), randomized resets, staggered episodes",
                        "envs_per_gpu": n, "rollout_chunk": T, "parallelism": f"env-sharded x{world}, RCCL gather per chunk" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)", "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n, "kernel": "so100_step_fused", "kernel_ms": kern_ms, "bytes_per_env_step": BYTES_PER_ENV_STEP,
-                         "kernel_env_steps_per_s": n / (kern_ms * 1e-3),
-                         "valu": {"achieved_tflops": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
-                                  "frac": FLOP_PER_ENV_STEP * n / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
+                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)", "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * units, "kernel": kernel_name, "kernel_ms": kern_ms, "env_steps_per_launch": units,
+                         "bytes_per_env_step": BYTES_PER_ENV_STEP, "kernel_env_steps_per_s": units / (kern_ms * 1e-3),
+                         "valu": {"achieved_tflops": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                                  "frac": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, flags, 3)
