@@ -313,9 +313,12 @@ template <int K, typename T> struct LinkCrb {
     }
 };
 
-template <typename T> SO100_HD void arm_dynamics(const T q[6], const T v[6], Arm<T>& A) {
+// stages of arm_dynamics (separately callable: the persistent rollout kernel runs arm_bias and arm_mass on different waves)
+template <typename T> SO100_HD void arm_trig(const T q[6], Arm<T>& A) {
 #pragma unroll
     for (int k = 0; k < 6; k++) tsincos<T>(q[k], A.s[k], A.c[k]);
+}
+template <typename T> SO100_HD void arm_bias(const T v[6], Arm<T>& A) {
     // RNEA (bias): base at rest, gravity folded in as a base acceleration of +g along world z
     T w[3] = { T(0), T(0), T(0) }, wd[3] = { T(0), T(0), T(0) }, a[3] = { T(0), T(0), T(so100g::GRAVITY) };
     T f[6][3], n[6][3];
@@ -331,6 +334,8 @@ template <typename T> SO100_HD void arm_dynamics(const T q[6], const T v[6], Arm
     LinkBwd<2, T>::run(A.s, A.c, f, n, A.bias);
     LinkBwd<1, T>::run(A.s, A.c, f, n, A.bias);
     LinkBwd<0, T>::run(A.s, A.c, f, n, A.bias);
+}
+template <typename T> SO100_HD void arm_mass(Arm<T>& A) {
     // CRBA
     Composite<T> cmp[6];
 #pragma unroll
@@ -347,6 +352,11 @@ template <typename T> SO100_HD void arm_dynamics(const T q[6], const T v[6], Arm
     LinkCrb<2, T>::run(A.s, A.c, cmp, A.M);
     LinkCrb<1, T>::run(A.s, A.c, cmp, A.M);
     LinkCrb<0, T>::run(A.s, A.c, cmp, A.M);
+}
+template <typename T> SO100_HD void arm_dynamics(const T q[6], const T v[6], Arm<T>& A) {
+    arm_trig(q, A);
+    arm_bias(v, A);
+    arm_mass(A);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,8 +439,8 @@ template <typename T> SO100_HD T impedance(T r) {
 //   iters       : PGS sweeps
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
-    arm_dynamics(q, v, A);
+SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+    // (A.M and A.bias hold this substep's mass matrix and bias force)
     // mj_fwdActuation: position servo kp (u - q) - kv qd, u clamped to ctrlrange, force to forcerange
     T tau[6];
 #pragma unroll
@@ -534,6 +544,12 @@ SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T f
         qc[i] = (t - q[i]) - y;
         q[i] = t;
     }
+}
+
+template <typename T>
+SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+    arm_dynamics(q, v, A);
+    arm_finish(q, v, qc, ctrl, ff, fl, flags, iters, A);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -4,8 +4,9 @@
 //   policy phase  (all 4 waves): the two hidden layers of both towers on the matrix cores (fp32 MFMA, weight
 //                 fragments resident in VGPRs for the whole launch, activations through LDS); the heads on the VALU:
 //                 wave 0 ends with the action of env = lane in registers.
-//   physics phase (wave 0 only):  the same fused env step as so100_step_fused (reward -> ctrl -> 16 substeps -> obs ->
-//                 TimeLimit -> auto-reset); the other waves sleep at the workgroup barrier.
+//   physics phase: the same fused env step as so100_step_fused (reward -> ctrl -> 16 substeps -> obs -> TimeLimit ->
+//                 auto-reset) for env = lane of wave 0, with each substep's RNEA bias force computed concurrently on
+//                 wave 1 (two workgroup barriers per substep; q, v and the bias cross through LDS).
 // The env state lives in wave 0's registers across all T steps (loaded once, stored once per launch), the
 // observation goes to the next policy phase through LDS, and the only per-step HBM traffic is the rollout-buffer row
 // (obs | action | reward | done | value | logp = (obs_dim+10) words per env).  Compared with one policy launch + one
@@ -43,6 +44,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
     __shared__ float h1t[2][64][LD];
     __shared__ float h2t[2][64][LD];
+    __shared__ float xq[12][64];                                  // physics split: q, v of env = lane (wave 0 -> wave 1)
+    __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,12 +74,13 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     }
     EnvState e;
     if (wave == 0) {
-        if (live) load_env_state<KIND>(state, p.n, env, e); else e = EnvState{};
+        if (live) load_env_state<KIND>(state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
 #pragma unroll
         for (int k = 0; k < ODP; k++) oxt[lane][k] = (live && k < OD) ? ra.obs_in[(size_t)env*OD + k] : 0.0f;
     }
     __syncthreads();
     StepResult last{}; float last_obs[OD];
+    StepCtx ctx{}; float ustep[8] = {}; float cstale[3] = {};
 #pragma unroll 1
     for (int t = 0; t < ra.T; t++) {
         // ---- layer 1: K = ODP
@@ -146,26 +150,72 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
 #pragma unroll
                 for (int k = 0; k < OD; k++) row[k] = oxt[lane][k];
                 row[OD + 9] = lp;
-                float obs[OD], tobs[OD];
-                const StepResult r = env_step_vec<KIND>(e, act, p, p.env_id_offset + (uint32_t)env, nullptr, start_tab, obs, tobs);
-                row[OD + 6] = r.reward; row[OD + 7] = r.done ? 1.0f : 0.0f;
-#pragma unroll
-                for (int k = 0; k < OD; k++) { oxt[lane][k] = obs[k]; last_obs[k] = obs[k]; }
-                last = r;
-                if (r.done) {
-                    if (tobs_out) {
-#pragma unroll
-                        for (int k = 0; k < OD; k++) tobs_out[(size_t)env*OD + k] = tobs[k];
-                    }
-                    if (ep_ret_out) ep_ret_out[env] = r.ep_return;
-                    if (ep_len_out) ep_len_out[env] = r.ep_length;
-                }
             }
+            draw8(p, p.env_id_offset + (uint32_t)env, (uint32_t)e.rngc, 0, nullptr, ustep);
+            e.rngc++;
+            env_step_pre<KIND>(e, act, ustep, p, ctx);
         } else if (wave == 2) {
             float v = hd[7*64 + 12];
 #pragma unroll 8
             for (int k = 0; k < 64; k++) v = __builtin_fmaf(hd[6*64 + k], h2t[1][lane][k], v);
             if (live) row[OD + 8] = v;
+        }
+        // ---- physics phase, split over the waves: per substep wave 1 computes the RNEA bias force while wave 0
+        //      computes the CRBA mass matrix and factorises it; wave 0 then solves, integrates and publishes q, v.
+        //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
+        {
+            Arm<float> A;
+            const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
+#pragma unroll 1
+            for (int sub = 0; sub < p.frame_skip; sub++) {
+                if (wave == 0) {
+                    cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { xq[i][lane] = e.q[i]; xq[6 + i][lane] = e.v[i]; }
+                }
+                __syncthreads();
+                if (wave == 1) {
+                    float q1[6], v1[6];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { q1[i] = xq[i][lane]; v1[i] = xq[6 + i][lane]; }
+                    arm_trig<float>(q1, A);
+                    arm_bias<float>(v1, A);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
+                } else if (wave == 0) {
+                    arm_trig<float>(e.q, A);
+                    arm_mass<float>(A);
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
+                    arm_finish<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+                    cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
+                }
+            }
+            if (wave == 0) {
+                e.nsub += p.frame_skip;
+                TaskPoses<float> P;
+                task_poses<float>(A.s, A.c, KIND >= 3, P);
+                float obs[OD], tobs[OD]; bool term;
+                const float reward = env_step_post<KIND>(e, ctx, ustep, P, cstale, obs, term);
+                const StepResult r = env_step_finish<KIND>(e, reward, term, p, p.env_id_offset + (uint32_t)env, nullptr, start_tab, obs, tobs);
+#pragma unroll
+                for (int k = 0; k < OD; k++) { oxt[lane][k] = obs[k]; last_obs[k] = obs[k]; }
+                last = r;
+                if (live) {
+                    row[OD + 6] = r.reward; row[OD + 7] = r.done ? 1.0f : 0.0f;
+                    if (r.done) {
+                        if (tobs_out) {
+#pragma unroll
+                            for (int k = 0; k < OD; k++) tobs_out[(size_t)env*OD + k] = tobs[k];
+                        }
+                        if (ep_ret_out) ep_ret_out[env] = r.ep_return;
+                        if (ep_len_out) ep_len_out[env] = r.ep_length;
+                    }
+                }
+            }
         }
         __syncthreads();
     }

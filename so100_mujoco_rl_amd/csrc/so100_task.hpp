@@ -251,60 +251,54 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
     task_poses<float>(A.s, A.c, want_cam, P);      // sin/cos of the angles the last substep STARTED from
 }
 
-// One EnvNN.step.  a = action, u = step-phase uniforms.  Returns reward; sets term; fills obs.
-template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const float u[8], const SimParams& p,
-                                             float* obs, bool& term) {
-    term = false;
+// One EnvNN.step, in three stages around the 16 physics substeps (the stepwise kernel runs them back to back; the
+// persistent rollout kernel runs the substeps on several waves in between):
+//   env_step_pre  : reward of the previous state (Q2), ctrl, Env02 reach branch / Env03-05 curriculum
+//   physics       : physics_substeps (or its multi-wave version)
+//   env_step_post : stale poses -> obs, look-at reward, termination
+struct StepCtx {
     float reward;
-    TaskPoses<float> P;
-    float cstale[3];
+    float ctrl[6];
+    float old[6], ncmd[6], frac, smin[3], smax[3];       // Env03-05
+};
+
+template <int KIND> SO100_HD void env_step_pre(EnvState& e, const float a[6], const float u[8], const SimParams& p, StepCtx& c) {
     if (KIND <= 2) {
         // ref: env01_v1.py:15-37 / env02_v1.py:18-50
-        reward = reward_base(e.q, e.cx, e.ee, e.wrist_z, (e.bits & B_HAS_PREV) != 0);
+        c.reward = reward_base(e.q, e.cx, e.ee, e.wrist_z, (e.bits & B_HAS_PREV) != 0);
         e.bits |= B_HAS_PREV;
-        float ctrl[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) ctrl[i] = e.q[i] + a[i]*JOINT_STEP_SCALE;
+        for (int i = 0; i < 6; i++) c.ctrl[i] = e.q[i] + a[i]*JOINT_STEP_SCALE;
         if (KIND == 2) {
             const float dx = e.cx[0] - e.ee[0], dy = e.cx[1] - e.ee[1], dz = e.cx[2] - e.ee[2];
             if (tsqrt(dx*dx + dy*dy + dz*dz) < 0.03f) {
                 const float bx = e.bp[0] - e.lbp[0], by = e.bp[1] - e.lbp[1], bz = e.bp[2] - e.lbp[2];
-                reward += tsqrt(bx*bx + by*by + bz*bz)*20.0f;
+                c.reward += tsqrt(bx*bx + by*by + bz*bz)*20.0f;
                 set_random_block_position(e, 2, 0.22f, u);
             }
         }
-        physics_substeps(e, ctrl, p, false, P, cstale);
-        // stale poses -> persistent (read by the next step's reward) and -> obs; ref: env_base_01.py:118-127, 241-270
-#pragma unroll
-        for (int i = 0; i < 3; i++) { e.ee[i] = P.jaw_pos[i] + P.jaw_mat[3*i + 1]*(-0.1f); e.cx[i] = cstale[i]; }
-        e.wrist_z = P.wrist[2];
-#pragma unroll
-        for (int i = 0; i < 6; i++) obs[i] = e.q[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { obs[6 + i] = e.cx[i] - e.ee[i]; obs[9 + i] = e.cx[i]; obs[12 + i] = e.ee[i]; }
     } else {
         // ref: env03_v1.py:124-201 (Env03, Env05) / env04_v1.py:62-160 (Env04)
         const float h = (float)so100g::TIMESTEP;
         const float time = (float)e.nsub*h;
-        const float frac = tmin(time/12.0f, 1.0f);
-        float smin[3], smax[3];
+        c.frac = tmin(time/12.0f, 1.0f);
 #pragma unroll
-        for (int i = 0; i < 3; i++) { smin[i] = SPACE_START[0][i]; smax[i] = SPACE_START[1][i]; }
+        for (int i = 0; i < 3; i++) { c.smin[i] = SPACE_START[0][i]; c.smax[i] = SPACE_START[1][i]; }
         if (KIND != 4) {
 #pragma unroll
             for (int i = 0; i < 3; i++) {                                  // _update_block_space :59-68
                 const float e0 = KIND == 5 ? SPACE_END_05[0][i] : SPACE_END_03[0][i];
                 const float e1 = KIND == 5 ? SPACE_END_05[1][i] : SPACE_END_03[1][i];
-                smin[i] = SPACE_START[0][i] + frac*(e0 - SPACE_START[0][i]);
-                smax[i] = SPACE_START[1][i] + frac*(e1 - SPACE_START[1][i]);
+                c.smin[i] = SPACE_START[0][i] + c.frac*(e0 - SPACE_START[0][i]);
+                c.smax[i] = SPACE_START[1][i] + c.frac*(e1 - SPACE_START[1][i]);
             }
-            const float speed = frac <= 0.05f ? 0.0f : (frac - 0.05f)*2.0f/(1.0f - 0.05f);   // :70-75
+            const float speed = c.frac <= 0.05f ? 0.0f : (c.frac - 0.05f)*2.0f/(1.0f - 0.05f);   // :70-75
             {                                                              // _update_block_target :77-93
                 const float tx = e.tgt[0] - e.cube.pos[0], ty = e.tgt[1] - e.cube.pos[1], tz = e.tgt[2] - e.cube.pos[2];
                 const float dist_t = tsqrt(tx*tx + ty*ty + tz*tz);
                 if (!(time - e.ttime < e.tdt && dist_t > 0.02f)) {
 #pragma unroll
-                    for (int i = 0; i < 3; i++) e.tgt[i] = smin[i] + (smax[i] - smin[i])*u[i];
+                    for (int i = 0; i < 3; i++) e.tgt[i] = c.smin[i] + (c.smax[i] - c.smin[i])*u[i];
                     e.tdt = 1.2f + (5.1f - 1.2f)*u[3];
                     e.ttime = time;
                 }
@@ -320,10 +314,28 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
                 }
             }
         }
-        float old[6], ncmd[6], ctrl[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) { old[i] = e.cmd[i]; ncmd[i] = e.cmd[i] + a[i]*JOINT_STEP_SCALE; ctrl[i] = ncmd[i]; }
-        physics_substeps(e, ctrl, p, true, P, cstale);
+        for (int i = 0; i < 6; i++) { c.old[i] = e.cmd[i]; c.ncmd[i] = e.cmd[i] + a[i]*JOINT_STEP_SCALE; c.ctrl[i] = c.ncmd[i]; }
+        c.reward = 0.0f;
+    }
+}
+
+template <int KIND> SO100_HD float env_step_post(EnvState& e, const StepCtx& c, const float u[8], const TaskPoses<float>& P,
+                                                  const float cstale[3], float* obs, bool& term) {
+    term = false;
+    float reward;
+    if (KIND <= 2) {
+        reward = c.reward;
+        // stale poses -> persistent (read by the next step's reward) and -> obs; ref: env_base_01.py:118-127, 241-270
+#pragma unroll
+        for (int i = 0; i < 3; i++) { e.ee[i] = P.jaw_pos[i] + P.jaw_mat[3*i + 1]*(-0.1f); e.cx[i] = cstale[i]; }
+        e.wrist_z = P.wrist[2];
+#pragma unroll
+        for (int i = 0; i < 6; i++) obs[i] = e.q[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { obs[6 + i] = e.cx[i] - e.ee[i]; obs[9 + i] = e.cx[i]; obs[12 + i] = e.ee[i]; }
+    } else {
+        const float h = (float)so100g::TIMESTEP;
         // ref: env05_v1.py:32-75 (Env03/04: the same reprojection stands in for render + YOLO, no noise)
         float cxn = -1.0f, cyn = -1.0f; int pu, pv;
         if (project(P.cam_pos, P.cam_mat, e.cube.pos, pu, pv)) {
@@ -331,7 +343,7 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
             if (KIND == 5) { cxn += -0.05f + 0.1f*u[4]; cyn += -0.05f + 0.1f*u[5]; }
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) obs[i] = old[i];
+        for (int i = 0; i < 6; i++) obs[i] = c.old[i];
         obs[6] = cxn; obs[7] = cyn;
         if (cxn == -1.0f && cyn == -1.0f) {                                // :152-164
             if (e.lost > 30) term = true;
@@ -348,19 +360,19 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
                 if (dd < 0.1f && !(e.bits & B_BLOCK_UPDATED)) {
                     e.bits |= B_BLOCK_UPDATED;
 #pragma unroll
-                    for (int i = 0; i < 3; i++) { e.tgt[i] = smin[i] + (smax[i] - smin[i])*u[i]; e.cube.pos[i] = e.tgt[i]; }
+                    for (int i = 0; i < 3; i++) { e.tgt[i] = c.smin[i] + (c.smax[i] - c.smin[i])*u[i]; e.cube.pos[i] = e.tgt[i]; }
                     reward += 10.0f;
                 }
             } else reward += -1.0f*dd;                                     // env03_v1.py:168-176
         }
-        reward += joint_reward(old);
+        reward += joint_reward(c.old);
         if (KIND == 4) {                                                   // env04_v1.py:137-148
-            const float wr = tclamp(joint_penalty(old[4], START_POSITION[4] - 0.2f, START_POSITION[4] + 0.2f), -0.2f, 0.0f);
+            const float wr = tclamp(joint_penalty(c.old[4], START_POSITION[4] - 0.2f, START_POSITION[4] + 0.2f), -0.2f, 0.0f);
             reward += wr*0.5f;
         } else {                                                           // env03_v1.py:182-189, env_base_01.py:165-178
             float pen = 0.0f, av[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) av[i] = (ncmd[i] - old[i])/h;
+            for (int i = 0; i < 6; i++) av[i] = (c.ncmd[i] - c.old[i])/h;
             if (e.bits & B_HAVE_ANGVEL) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) pen += tabs(av[i] - e.av[i])*0.0025f;
@@ -368,17 +380,30 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
 #pragma unroll
             for (int i = 0; i < 6; i++) e.av[i] = av[i];
             e.bits |= B_HAVE_ANGVEL;
-            reward += (-pen)*frac;
+            reward += (-pen)*c.frac;
         }
         obs[6] = 5.0f*obs[6]; obs[7] = 5.0f*obs[7];                        // :195-196 (Q4)
 #pragma unroll
-        for (int i = 0; i < 6; i++) e.cmd[i] = ncmd[i];                    // :198
+        for (int i = 0; i < 6; i++) e.cmd[i] = c.ncmd[i];                  // :198
     }
     return reward;
 }
 
+template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const float u[8], const SimParams& p,
+                                             float* obs, bool& term) {
+    StepCtx c;
+    env_step_pre<KIND>(e, a, u, p, c);
+    TaskPoses<float> P;
+    float cstale[3];
+    physics_substeps(e, c.ctrl, p, KIND >= 3, P, cstale);
+    return env_step_post<KIND>(e, c, u, P, cstale, obs, term);
+}
+
 // Env.step + gymnasium TimeLimit + SB3 DummyVecEnv auto-reset, for one env
 struct StepResult { float reward; bool done, trunc_only; float ep_return; int ep_length; };
+
+template <int KIND> SO100_HD StepResult env_step_finish(EnvState& e, float reward, bool term, const SimParams& p, uint32_t env_gid,
+                                                         const float* inject, const float* start_tab, float* obs, float* terminal_obs);
 
 template <int KIND> SO100_HD StepResult env_step_vec(EnvState& e, const float a[6], const SimParams& p, uint32_t env_gid,
                                                       const float* inject, const float* start_tab, float* obs, float* terminal_obs) {
@@ -386,8 +411,16 @@ template <int KIND> SO100_HD StepResult env_step_vec(EnvState& e, const float a[
     draw8(p, env_gid, (uint32_t)e.rngc, 0, inject, u);
     e.rngc++;
     bool term;
+    const float reward = env_step<KIND>(e, a, u, p, obs, term);
+    return env_step_finish<KIND>(e, reward, term, p, env_gid, inject, start_tab, obs, terminal_obs);
+}
+
+// TimeLimit + episode statistics + auto-reset (the tail of env_step_vec; u8 scratch is drawn here for the reset phase)
+template <int KIND> SO100_HD StepResult env_step_finish(EnvState& e, float reward, bool term, const SimParams& p, uint32_t env_gid,
+                                                         const float* inject, const float* start_tab, float* obs, float* terminal_obs) {
+    float u[8];
     StepResult r;
-    r.reward = env_step<KIND>(e, a, u, p, obs, term);
+    r.reward = reward;
     e.elapsed++;
     const bool trunc = p.max_episode_steps > 0 && e.elapsed >= p.max_episode_steps;
     e.epret += r.reward; e.eplen++;
