@@ -208,29 +208,39 @@ template <int AX, typename T> SO100_HD void sym_rot_axis(const T A[6], T s, T c,
 // ---------------------------------------------------------------------------------------------
 template <typename T> struct Arm {
     T s[6], c[6];          // sin/cos of the joint angles
-    T M[21];               // M[i(i+1)/2 + j], j <= i
+    T M[21];               // M[i(i+1)/2 + j], j <= i   (after arm_factor: the LDL^T factor)
     T bias[6];
+    T Dinv[6], Minv[21];   // arm_factor: 1/D of the factor; explicit inverse (constrained variants only)
 };
 
 template <int K, typename T> struct LinkFwd {            // RNEA forward step for link K
     SO100_HD static void run(const T s[6], const T c[6], const T v[6], T w[3], T wd[3], T a[3],
                              T f[6][3], T n[6][3]) {
         constexpr int AX = so100g::LINK_AXIS[K];
-        // acceleration of this link's origin, in parent coords: a + wd x p + w x (w x p)
-        T t1[3], t2[3], ao[3];
-        crossp<K>(wd, t1); crossp<K>(w, t2); cross(w, t2, t2);
-        ao[0] = a[0] + t1[0] + t2[0]; ao[1] = a[1] + t1[1] + t2[1]; ao[2] = a[2] + t1[2] + t2[2];
-        T wc[3], wdc[3];
-        to_child<K>(w, s[K], c[K], wc);
-        to_child<K>(wd, s[K], c[K], wdc);
-        to_child<K>(ao, s[K], c[K], a);
-        // wd_k = E^T wd_p + (E^T w_p) x (axis qd);  w_k = E^T w_p + axis qd
         constexpr int B = (AX + 1) % 3, C = (AX + 2) % 3;
         const T qd = v[K];
-        wdc[B] += wc[C]*qd; wdc[C] -= wc[B]*qd;
-        wc[AX] += qd;
-        w[0] = wc[0]; w[1] = wc[1]; w[2] = wc[2];
-        wd[0] = wdc[0]; wd[1] = wdc[1]; wd[2] = wdc[2];
+        if constexpr (K == 0) {
+            // the base is at rest: w_p = wd_p = 0, so the origin acceleration is the base's (gravity) and
+            // w = axis qd, wd = 0 (the generic code below would spend ~40 instructions multiplying zeros)
+            T ao[3] = { a[0], a[1], a[2] };
+            to_child<K>(ao, s[K], c[K], a);
+            w[AX] = qd; w[B] = T(0); w[C] = T(0);
+            wd[0] = T(0); wd[1] = T(0); wd[2] = T(0);
+        } else {
+            // acceleration of this link's origin, in parent coords: a + wd x p + w x (w x p)
+            T t1[3], t2[3], ao[3];
+            crossp<K>(wd, t1); crossp<K>(w, t2); cross(w, t2, t2);
+            ao[0] = a[0] + t1[0] + t2[0]; ao[1] = a[1] + t1[1] + t2[1]; ao[2] = a[2] + t1[2] + t2[2];
+            T wc[3], wdc[3];
+            to_child<K>(w, s[K], c[K], wc);
+            to_child<K>(wd, s[K], c[K], wdc);
+            to_child<K>(ao, s[K], c[K], a);
+            // wd_k = E^T wd_p + (E^T w_p) x (axis qd);  w_k = E^T w_p + axis qd
+            wdc[B] += wc[C]*qd; wdc[C] -= wc[B]*qd;
+            wc[AX] += qd;
+            w[0] = wc[0]; w[1] = wc[1]; w[2] = wc[2];
+            wd[0] = wdc[0]; wd[1] = wdc[1]; wd[2] = wdc[2];
+        }
         // spatial force about the link origin:  f = m a + wd x h + w x (w x h),  n = Io wd + w x (Io w) + h x a
         const T h[3] = { T(so100g::LINK_H[K][0]), T(so100g::LINK_H[K][1]), T(so100g::LINK_H[K][2]) };
         const T Io[6] = { T(so100g::LINK_IORG[K][0]), T(so100g::LINK_IORG[K][1]), T(so100g::LINK_IORG[K][2]),
@@ -439,8 +449,16 @@ template <typename T> SO100_HD T impedance(T r) {
 //   iters       : PGS sweeps
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
-    // (A.M and A.bias hold this substep's mass matrix and bias force)
+SO100_HD void arm_factor(unsigned flags, Arm<T>& A) {
+    // needs only A.M: LDL^T in place (+ the explicit inverse when constraint rows are simulated)
+    ldl6(A.M, A.Dinv);
+    if ((flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u) ldl6_inverse(A.M, A.Dinv, A.Minv);
+}
+
+template <typename T>
+SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+    // (A.M / A.Dinv / A.Minv hold this substep's factorised mass matrix, A.bias its bias force)
+    const T* Dinv = A.Dinv; const T* Minv = A.Minv;
     // mj_fwdActuation: position servo kp (u - q) - kv qd, u clamped to ctrlrange, force to forcerange
     T tau[6];
 #pragma unroll
@@ -450,16 +468,13 @@ SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl
         f = tclamp(f, T(-so100g::ACT_FORCE), T(so100g::ACT_FORCE));
         tau[i] = f - A.bias[i];
     }
-    T Dinv[6], acc[6];
-    ldl6(A.M, Dinv);
+    T acc[6];
     const bool constrained = (flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u;
     if (!constrained) {
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[i] = tau[i];
         ldl6_solve(A.M, Dinv, acc);
     } else {
-        T Minv[21];
-        ldl6_inverse(A.M, Dinv, Minv);
         T a0[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
@@ -544,6 +559,12 @@ SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl
         qc[i] = (t - q[i]) - y;
         q[i] = t;
     }
+}
+
+template <typename T>
+SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+    arm_factor(flags, A);
+    arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, iters, A);
 }
 
 template <typename T>

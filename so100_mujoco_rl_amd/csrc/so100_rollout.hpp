@@ -185,12 +185,13 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 } else if (wave == 0) {
                     arm_trig<float>(e.q, A);
                     arm_mass<float>(A);
+                    arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
                 }
                 __syncthreads();
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
-                    arm_finish<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+                    arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
                     cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
                 }
             }

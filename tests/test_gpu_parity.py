@@ -365,10 +365,11 @@ def test_rollout_collector_and_vecenv():
     for t in range(T):
         a = b["actions"][t].cpu().numpy()
         ob, r, d, infos = env2.step(np.clip(a, -1, 1))
-        np.testing.assert_array_equal(r, b["rewards"][t].cpu().numpy())
+        # the persistent kernel and so100_step_fused are separate compilations of the same code: results agree to an ulp
+        np.testing.assert_allclose(r, b["rewards"][t].cpu().numpy(), rtol=0, atol=1e-6)
         np.testing.assert_array_equal(d.astype(np.float32), b["dones"][t].cpu().numpy())
         if t + 1 < T:
-            np.testing.assert_array_equal(ob, b["obs"][t + 1].cpu().numpy())
+            np.testing.assert_allclose(ob, b["obs"][t + 1].cpu().numpy(), rtol=0, atol=1e-6)
         for i in np.nonzero(d)[0]:
             assert infos[i]["TimeLimit.truncated"] is True and infos[i]["terminal_observation"].shape == (15,)
             assert infos[i]["episode"]["l"] == 5
