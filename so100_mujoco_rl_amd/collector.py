@@ -15,13 +15,16 @@ from .rollout import RolloutChunk, gather_rollout
 
 
 class RolloutCollector:
-    def __init__(self, vec_env, state_dict, T=64, persistent=True):
+    def __init__(self, vec_env, state_dict, T=64, persistent=None):
         self.env = vec_env; self.sim = vec_env.sim
         self.T = T
         self.chunk = RolloutChunk(T, self.sim.n, self.sim.obs_dim, self.sim.device)
         self.act = torch.zeros(self.sim.n, 6, device=self.sim.device)
         self.counter = 0
-        self.persistent = persistent            # one launch per chunk (so100_rollout) vs two launches per step
+        # one launch per chunk (so100_rollout: lowest latency, but one physics wave per CU => best up to 256 CUs x 64
+        # envs) vs two launches per step (so100_policy_forward + so100_step: every lane computes physics => best
+        # throughput for large batches).  Measured on MI355X: 4096 envs 110 M vs 68 M env-steps/s; 65536 envs 0.44 G vs 1.0 G.
+        self.persistent = (self.sim.n <= 16384) if persistent is None else persistent
         self.load_policy(state_dict)
         self._started = False
 
