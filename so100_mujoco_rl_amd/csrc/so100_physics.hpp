@@ -328,6 +328,23 @@ template <typename T> SO100_HD void arm_trig(const T q[6], Arm<T>& A) {
 #pragma unroll
     for (int k = 0; k < 6; k++) tsincos<T>(q[k], A.s[k], A.c[k]);
 }
+// sin/cos of q + dq from those of q: a rotation by dq with Taylor series for sin dq / cos dq (|dq| = h |qd| < 0.1 rad:
+// truncation < 1e-11).  fp32 only: 66 instructions instead of ~150 for six fresh sin/cos pairs; the fp64 (host-test)
+// instantiation recomputes exact trig so that the formulation-equivalence tests keep their 1e-13 tolerances.
+// Round-off accumulates over at most frame_skip-1 updates (~2e-7): arm_trig() resynchronises at every env step.
+template <typename T> SO100_HD void arm_trig_update(const T q[6], const T dq[6], Arm<T>& A) {
+    if constexpr (sizeof(T) == 8) { arm_trig(q, A); }
+    else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const T d = dq[k], d2 = d*d;
+            const T sd = d*(T(1) + d2*(T(-1.0/6.0) + d2*T(1.0/120.0)));
+            const T cd = T(1) + d2*(T(-0.5) + d2*(T(1.0/24.0) + d2*T(-1.0/720.0)));
+            const T sn = A.s[k]*cd + A.c[k]*sd, cs = A.c[k]*cd - A.s[k]*sd;
+            A.s[k] = sn; A.c[k] = cs;
+        }
+    }
+}
 template <typename T> SO100_HD void arm_bias(const T v[6], Arm<T>& A) {
     // RNEA (bias): base at rest, gravity folded in as a base acceleration of +g along world z
     T w[3] = { T(0), T(0), T(0) }, wd[3] = { T(0), T(0), T(0) }, a[3] = { T(0), T(0), T(so100g::GRAVITY) };
@@ -456,7 +473,7 @@ SO100_HD void arm_factor(unsigned flags, Arm<T>& A) {
 }
 
 template <typename T>
-SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6]) {
     // (A.M / A.Dinv / A.Minv hold this substep's factorised mass matrix, A.bias its bias force)
     const T* Dinv = A.Dinv; const T* Minv = A.Minv;
     // mj_fwdActuation: position servo kp (u - q) - kv qd, u clamped to ctrlrange, force to forcerange
@@ -558,19 +575,24 @@ SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff
         const T y = h*v[i] - qc[i], t = q[i] + y;
         qc[i] = (t - q[i]) - y;
         q[i] = t;
+        dq[i] = y;                              // the (compensated) increment: what the next substep's trig update rotates by
     }
 }
 
 template <typename T>
-SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
+SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6]) {
     arm_factor(flags, A);
-    arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, iters, A);
+    arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, iters, A, dq);
 }
 
 template <typename T>
-SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A) {
-    arm_dynamics(q, v, A);
-    arm_finish(q, v, qc, ctrl, ff, fl, flags, iters, A);
+SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A,
+                          bool first, T dq[6]) {
+    // first substep of an env step: exact sin/cos; later ones: incremental update by the previous substep's increment
+    if (first) arm_trig(q, A); else arm_trig_update(q, dq, A);
+    arm_bias(v, A);
+    arm_mass(A);
+    arm_finish(q, v, qc, ctrl, ff, fl, flags, iters, A, dq);
 }
 
 // ---------------------------------------------------------------------------------------------

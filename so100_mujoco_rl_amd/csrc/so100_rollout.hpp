@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
     __shared__ float h1t[2][64][LD];
     __shared__ float h2t[2][64][LD];
-    __shared__ float xq[12][64];                                  // physics split: q, v of env = lane (wave 0 -> wave 1)
+    __shared__ float xq[18][64];                                  // physics split: sin q, cos q, v of env = lane (wave 0 -> wave 1)
     __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
@@ -165,25 +165,26 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
+            float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
             const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
 #pragma unroll 1
             for (int sub = 0; sub < p.frame_skip; sub++) {
                 if (wave == 0) {
                     cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];
+                    // sin/cos: exact at the first substep, then rotated by the integration increment (arm_substep does the same)
+                    if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
 #pragma unroll
-                    for (int i = 0; i < 6; i++) { xq[i][lane] = e.q[i]; xq[6 + i][lane] = e.v[i]; }
+                    for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
                 }
                 __syncthreads();
                 if (wave == 1) {
-                    float q1[6], v1[6];
+                    float v1[6];
 #pragma unroll
-                    for (int i = 0; i < 6; i++) { q1[i] = xq[i][lane]; v1[i] = xq[6 + i][lane]; }
-                    arm_trig<float>(q1, A);
+                    for (int i = 0; i < 6; i++) { A.s[i] = xq[i][lane]; A.c[i] = xq[6 + i][lane]; v1[i] = xq[12 + i][lane]; }
                     arm_bias<float>(v1, A);
 #pragma unroll
                     for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
                 } else if (wave == 0) {
-                    arm_trig<float>(e.q, A);
                     arm_mass<float>(A);
                     arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
                 }
@@ -191,7 +192,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
-                    arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+                    arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
                     cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
                 }
             }

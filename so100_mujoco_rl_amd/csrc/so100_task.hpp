@@ -240,11 +240,12 @@ template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const
 SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams& p, bool want_cam,
                                TaskPoses<float>& P, float cube_stale[3]) {
     Arm<float> A;
+    float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
 #pragma unroll 1
     for (int s = 0; s < p.frame_skip; s++) {
         cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
-        arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A);
+        arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, s == 0, dq);
         cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
     }
     e.nsub += p.frame_skip;

@@ -13,8 +13,8 @@ template <typename T> static void dyn(const double* q, const double* v, double* 
 template <typename T> static void sub(double* q, double* v, const double* ctrl, double* ff, double* fl, unsigned flags, int iters, int n) {
     T qq[6], vv[6], cc[6], f1[6], f2[6], qc[6] = {0,0,0,0,0,0};
     for (int i = 0; i < 6; i++) { qq[i] = (T)q[i]; vv[i] = (T)v[i]; cc[i] = (T)ctrl[i]; f1[i] = (T)ff[i]; f2[i] = (T)fl[i]; }
-    Arm<T> A;
-    for (int s = 0; s < n; s++) arm_substep(qq, vv, qc, cc, f1, f2, flags, iters, A);
+    Arm<T> A; T dq[6] = {0,0,0,0,0,0};
+    for (int s = 0; s < n; s++) arm_substep(qq, vv, qc, cc, f1, f2, flags, iters, A, (s % 16) == 0, dq);
     for (int i = 0; i < 6; i++) { q[i] = qq[i]; v[i] = vv[i]; ff[i] = f1[i]; fl[i] = f2[i]; }
 }
 template <typename T> static void poses(const double* q, double* out /*3+3+9+3+9*/) {
