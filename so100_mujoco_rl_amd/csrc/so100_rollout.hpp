@@ -6,7 +6,8 @@
 //                 wave 0 ends with the action of env = lane in registers.
 //   physics phase: the same fused env step as so100_step_fused (reward -> ctrl -> 16 substeps -> obs -> TimeLimit ->
 //                 auto-reset) for env = lane of wave 0, with each substep's RNEA bias force computed concurrently on
-//                 wave 1 (two workgroup barriers per substep; q, v and the bias cross through LDS).
+//                 wave 1 and, when the cube is simulated, its free-body / floor-contact substep on wave 2 (two workgroup
+//                 barriers per substep; sin/cos, q-dot, the bias and the cube state cross through LDS).
 // The env state lives in wave 0's registers across all T steps (loaded once, stored once per launch), the
 // observation goes to the next policy phase through LDS, and the only per-step HBM traffic is the rollout-buffer row
 // (obs | action | reward | done | value | logp = (obs_dim+10) words per env).  Compared with one policy launch + one
@@ -45,6 +46,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __shared__ float h1t[2][64][LD];
     __shared__ float h2t[2][64][LD];
     __shared__ float xq[18][64];                                  // physics split: sin q, cos q, v of env = lane (wave 0 -> wave 1)
+    __shared__ float xc[24][64];                                  //                cube state hand-over (wave 0 <-> wave 2)
     __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
@@ -166,11 +168,37 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         {
             Arm<float> A;
             float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
+            // The cube is dynamically independent of the arm: when it is simulated (not pinned) wave 2 owns it for the
+            // substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
+            const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
+            Cube<float> cb;
+            float applied[3] = { 0.0f, 0.0f, 0.0f };
+            if (cube_live) {
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) xc[i][lane] = e.cube.pos[i];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) xc[3 + i][lane] = e.cube.quat[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { xc[7 + i][lane] = e.cube.vel[i]; xc[13 + i][lane] = e.cube.warm[i]; }
+                    xc[19][lane] = (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f;
+                }
+                __syncthreads();
+                if (wave == 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) cb.pos[i] = xc[i][lane];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) cb.quat[i] = xc[3 + i][lane];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { cb.vel[i] = xc[7 + i][lane]; cb.warm[i] = xc[13 + i][lane]; }
+                    applied[2] = xc[19][lane];
+                }
+            } else if (wave == 0) {
+                cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];      // kinematic cube
+            }
 #pragma unroll 1
             for (int sub = 0; sub < p.frame_skip; sub++) {
                 if (wave == 0) {
-                    cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];
                     // sin/cos: exact at the first substep, then rotated by the integration increment (arm_substep does the same)
                     if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
 #pragma unroll
@@ -187,13 +215,34 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 } else if (wave == 0) {
                     arm_mass<float>(A);
                     arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
+                } else if (wave == 2 && cube_live) {
+                    if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
+                    cube_substep<float>(cb, applied, p.flags, p.contact_iters);
                 }
                 __syncthreads();
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
                     arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
-                    cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
+                }
+            }
+            if (cube_live) {
+                if (wave == 2) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) xc[i][lane] = cb.pos[i];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) xc[3 + i][lane] = cb.quat[i];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { xc[7 + i][lane] = cb.vel[i]; xc[13 + i][lane] = cb.warm[i]; }
+                }
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { e.cube.pos[i] = xc[i][lane]; cstale[i] = xc[20 + i][lane]; }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) e.cube.quat[i] = xc[3 + i][lane];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { e.cube.vel[i] = xc[7 + i][lane]; e.cube.warm[i] = xc[13 + i][lane]; }
                 }
             }
             if (wave == 0) {
