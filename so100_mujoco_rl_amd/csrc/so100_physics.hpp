@@ -156,23 +156,6 @@ template <typename T> SO100_HD void sym_mul(const T I[6], const T v[3], T r[3]) 
 SO100_HD constexpr int sym_idx(int i, int j) {
     return i == j ? i : ((i + j == 1) ? 3 : ((i + j == 2) ? 4 : 5));
 }
-// B = R A R^T for a general 3x3 R (row-major) and symmetric A
-template <typename T> SO100_HD void sym_similarity(const T R[9], const T A[6], T Bm[6]) {
-    T t[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const T r0 = R[3*i], r1 = R[3*i+1], r2 = R[3*i+2];
-        t[3*i]   = r0*A[0] + r1*A[3] + r2*A[4];
-        t[3*i+1] = r0*A[3] + r1*A[1] + r2*A[5];
-        t[3*i+2] = r0*A[4] + r1*A[5] + r2*A[2];
-    }
-    Bm[0] = t[0]*R[0] + t[1]*R[1] + t[2]*R[2];
-    Bm[1] = t[3]*R[3] + t[4]*R[4] + t[5]*R[5];
-    Bm[2] = t[6]*R[6] + t[7]*R[7] + t[8]*R[8];
-    Bm[3] = t[0]*R[3] + t[1]*R[4] + t[2]*R[5];
-    Bm[4] = t[0]*R[6] + t[1]*R[7] + t[2]*R[8];
-    Bm[5] = t[3]*R[6] + t[4]*R[7] + t[5]*R[8];
-}
 // B = C_K A C_K^T with the constant, sparse link rotation C_K
 template <int K, typename T> SO100_HD void sym_similarity_c(const T A[6], T Bm[6]) {
     T t[9];                                                   // t = C A
