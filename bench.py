@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_reference", "env02_reference", "env05_reference"])
+    ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_arm", "env01_reference", "env02_reference", "env05_reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--policy", default="persistent", choices=["persistent", "fused", "torch"])
     args = ap.parse_args()
@@ -101,11 +101,15 @@ def main():
         sys.exit("bench.py needs a HIP device (there is no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # SO100_FORCE_DIST=1 runs the distributed code path (RCCL init, async gather, barrier, all-reduce) even with one
+    # rank: a way to exercise it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("SO100_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE
-    kind, flags = {"env01_free": (1, F_CUBE_PINNED), "env01_reference": (1, F_REFERENCE),
+    from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE, F_FRICTIONLOSS, F_LIMITS
+    kind, flags = {"env01_free": (1, F_CUBE_PINNED), "env01_arm": (1, F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED), "env01_reference": (1, F_REFERENCE),
                    "env02_reference": (2, F_REFERENCE), "env05_reference": (5, F_REFERENCE)}[args.workload]
     n = args.envs
     sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=3, contact_iters=4, seed=1234 + rank, env_id_offset=rank * n)
@@ -118,8 +122,8 @@ def main():
     k = sim.obs_dim + 6 + 4                                  # obs, action, reward, done, value, logp
     # two chunk buffers: while chunk i is gathered to the learner over RCCL (async, on the collective's own stream),
     # the next rollout chunk is already being produced into buffer 1-i
-    chunks = [torch.zeros(T, n, k, device=dev) for _ in range(2 if world > 1 else 1)]
-    gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    chunks = [torch.zeros(T, n, k, device=dev) for _ in range(2 if use_dist else 1)]
+    gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
     pending = [None, None]
     noise = torch.empty(n, 6, device=dev)
 
@@ -157,7 +161,7 @@ def main():
                         a = a.clamp_(-1.0, 1.0)
                         ob, rew, done, trunc = sim.step(a)
                         row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
-            if world > 1:
+            if use_dist:
                 # RCCL: rollout chunk -> learner rank.  The collective is ordered after the producing kernel on this
                 # stream and runs on its own stream; nothing waits for it until this buffer is reused (two chunks later).
                 pending[ci] = dist.gather(chunk, [gb[:Tc] for gb in gathered] if gathered is not None else None, dst=0, async_op=True)
@@ -166,7 +170,7 @@ def main():
         for i, wk in enumerate(pending):
             if wk is not None:
                 wk.wait(); pending[i] = None
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -176,7 +180,7 @@ def main():
     run(args.steps)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
 
     # dominant kernel alone: HIP events on the launch stream (torch's current stream, where the C ABI enqueues) around
@@ -232,7 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, flags, 3)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 
