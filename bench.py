@@ -28,7 +28,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = 452.0        # SURVEY.md section 8(d), Env01, fp32 SoA, 16 substeps fused
-FLOP_PER_ENV_STEP = 6.0e4         # SURVEY.md section 8(d), constraint-free
+FLOP_PER_ENV_STEP_SURVEY = 6.0e4  # SURVEY.md section 8(d) estimate, constraint-free
+# measured: PMC SQ_INSTS_VALU = 22.95 k VALU instructions per env-step lane (profiles/r01_c), of which ~45 % are FMAs
+# (ISA count: 1017 fma/fmac of 2100 float ops per substep) => ~1.45 FLOP per instruction => 3.3e4 FLOP per env-step.
+# The VALU fraction below uses the MEASURED figure (the survey estimate would overstate utilisation 1.8x).
+FLOP_PER_ENV_STEP = 3.3e4
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3
 ROLLOUT_T = 64
@@ -84,6 +88,30 @@ def cpu_baseline(kind, flags, iters, seconds=12.0):
             "sample": f"{n} Env01 envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads, same flags/solver iterations"}
 
 
+def large_batch_roofline(kind, flags, dev, n=1 << 20, reps=20):
+    """Supplementary: the same fused env-step kernel (so100_step_fused, every lane computes physics) with the chip
+    filled -- 1,048,576 envs (0.37 GB of state) -- priced with the same 452 B / 3.3e4 FLOP per env-step.  At the BASELINE
+    batch of 4096 envs (64 physics waves on 1024 SIMDs) no kernel can approach a roofline; this is what the kernel
+    sustains when it can."""
+    from so100_mujoco_rl_amd.lib import So100Sim
+    sim = So100Sim(kind, n, device=dev, flags=flags, seed=99)
+    sim.reset()
+    a = (torch.rand(n, 6, device=dev) * 2 - 1).contiguous()
+    for _ in range(3):
+        sim.step(a)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev); e0.record()
+    for _ in range(reps):
+        sim.step(a)
+    e1.record(); torch.cuda.synchronize(dev)
+    ms = e0.elapsed_time(e1) / reps
+    sim.close()
+    gbs = BYTES_PER_ENV_STEP * n / (ms * 1e-3) / 1e9
+    tf = FLOP_PER_ENV_STEP * n / (ms * 1e-3) / 1e12
+    return {"kernel": "so100_step_fused", "envs": n, "kernel_ms": ms, "env_steps_per_s": n / (ms * 1e-3),
+            "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "valu_tflops": tf, "valu_frac": tf / VALU_PEAK_TFLOPS}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +120,7 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_arm", "env01_reference", "env02_reference", "env05_reference"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the supplementary 1M-env kernel measurement")
     ap.add_argument("--policy", default="persistent", choices=["persistent", "fused", "torch"])
     args = ap.parse_args()
 
@@ -230,11 +259,14 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)", "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * units, "kernel": kernel_name, "kernel_ms": kern_ms, "env_steps_per_launch": units,
                          "bytes_per_env_step": BYTES_PER_ENV_STEP, "kernel_env_steps_per_s": units / (kern_ms * 1e-3),
-                         "valu": {"achieved_tflops": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
+                         "valu": {"flop_per_env_step": FLOP_PER_ENV_STEP, "flop_per_env_step_survey_estimate": FLOP_PER_ENV_STEP_SURVEY,
+                                  "achieved_tflops": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
                                   "frac": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, flags, 3)
+        if world == 1 and args.workload == "env01_free" and not args.no_large_batch:
+            out["roofline"]["large_batch"] = large_batch_roofline(kind, flags, dev)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()

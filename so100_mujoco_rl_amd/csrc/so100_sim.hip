@@ -63,8 +63,11 @@ struct StepPtrs {
 //     -> TimeLimit -> auto-reset), SURVEY.md section 8a rows a1-a10.
 // FL >= 0: the physics flags are a compile-time constant (dead constraint families are not even compiled in:
 // fewer live registers, smaller loop body); FL < 0: flags read from the handle at run time.
+// The constraint-free variant fits 256 registers: asking for 2 waves per SIMD keeps the latency hiding that large
+// batches need (1 M envs: 2 waves/SIMD 2.3 G env-steps/s, 1 wave/SIMD 1.5 G); the constrained variants and the
+// look-at envs (more task state) need > 256 and would spill.
 template <int KIND, int FL>
-__global__ void __launch_bounds__(WG) so100_step_fused(SimParams p, StepPtrs io) {
+__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && KIND <= 2) ? 2 : 1)) so100_step_fused(SimParams p, StepPtrs io) {
     const int env = blockIdx.x*WG + threadIdx.x;
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
