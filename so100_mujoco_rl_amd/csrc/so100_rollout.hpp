@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
             // The cube is dynamically independent of the arm: when it is simulated (not pinned) wave 2 owns it for the
             // substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
             const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
-            Cube<float> cb;
+            Cube<float> cb; CubePrep<float> cprep;
             float applied[3] = { 0.0f, 0.0f, 0.0f };
             if (cube_live) {
                 if (wave == 0) {
@@ -217,9 +217,10 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                     arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
                 } else if (wave == 2 && cube_live) {
                     if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
-                    cube_substep<float>(cb, applied, p.flags, p.contact_iters);
+                    cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
                 }
                 __syncthreads();
+                if (wave == 2 && cube_live) cube_finish<float>(cb, p.flags, p.contact_iters, cprep);   // ... Newton + Euler behind the arm's solve
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
