@@ -141,7 +141,7 @@ def main():
     kind, flags = {"env01_free": (1, F_CUBE_PINNED), "env01_arm": (1, F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED), "env01_reference": (1, F_REFERENCE),
                    "env02_reference": (2, F_REFERENCE), "env05_reference": (5, F_REFERENCE)}[args.workload]
     n = args.envs
-    sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=3, contact_iters=6, seed=1234 + rank, env_id_offset=rank * n)
+    sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=2, contact_iters=6, seed=1234 + rank, env_id_offset=rank * n)
     obs = sim.reset()
     # stagger the episodes so TimeLimit resets are spread over the rollout
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)
@@ -264,7 +264,7 @@ def main():
                                   "frac": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, flags, 3)
+            out["cpu_baseline"] = cpu_baseline(kind, flags, 2)
         if world == 1 and args.workload == "env01_free" and not args.no_large_batch:
             out["roofline"]["large_batch"] = large_batch_roofline(kind, flags, dev)
         print(json.dumps(out), flush=True)
