@@ -65,3 +65,16 @@ def test_library_binds_one_hip_runtime(L):
     maps = open("/proc/self/maps").read()
     libs = sorted(set(re.findall(r"(/\S*libamdhip64\S*)", maps)))
     assert len(libs) == 1, libs
+
+
+def test_integration_doc_matches_abi():
+    """The ctypes stub printed in INTEGRATION.md must list exactly the fields of so100_config / so100_step_io."""
+    from so100_mujoco_rl_amd import lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    io_names = re.findall(r'"(\w+_dev)"', doc.split("class IO")[1].split("lib.so100_last_error")[0])
+    assert io_names == [f[0] for f in lib.StepIO._fields_]
+    cfg_names = re.findall(r'\("(\w+)", C\.c_', doc.split("class Cfg")[1].split("class IO")[0])
+    assert cfg_names == [f[0] for f in lib.Config._fields_]
+    hdr = open(os.path.join(ROOT, "include", "so100_sim.h")).read()
+    step_io = hdr.split("typedef struct {", 3)[2].split("} so100_step_io;")[0]
+    assert re.findall(r"(\w+_dev);", step_io) == io_names

@@ -476,3 +476,39 @@ def test_soak_full_batch(kind, flags, n):
     if not (flags & O.F_CUBE_PINNED):
         assert q[8].min() > -0.02                             # the cube never falls through the floor
         assert (torch.linalg.vector_norm(q[9:13], dim=0) - 1).abs().max() < 1e-5
+
+
+def test_stepwise_calls_are_graph_capturable():
+    """so100_policy_forward + so100_step enqueue on the caller's stream without allocating or synchronising, so a
+    rollout step can be captured into a hipGraph (torch.cuda.CUDAGraph) and replayed; replay == eager."""
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n, T = 512, 6
+    outs = []
+    for use_graph in (False, True):
+        sim = _sim(1, n, flags=ARM, seed=8)
+        sd = RolloutCollector.random_policy_state(15, sim.device, seed=4)
+        from so100_mujoco_rl_amd.lib import POLICY_TENSORS, SB3_STATE_DICT_KEYS
+        sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
+        sim.reset()
+        act = torch.zeros(n, 6, device="cuda"); row = torch.zeros(n, 25, device="cuda")
+        rows = []
+        if use_graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                # the policy-noise counter is a launch argument: one graph per counter value would be needed to vary it,
+                # so this check replays a fixed-noise step (the env's own RNG counter lives in device state and advances)
+                with torch.cuda.graph(g, stream=s):
+                    sim.policy_forward(sim.obs, act, 0, rollout_row=row)
+                    sim.step(act, rollout_row=row)
+            torch.cuda.current_stream().wait_stream(s)
+            for t in range(T):
+                g.replay(); rows.append(row.clone())
+        else:
+            for t in range(T):
+                sim.policy_forward(sim.obs, act, 0, rollout_row=row)
+                sim.step(act, rollout_row=row); rows.append(row.clone())
+        torch.cuda.synchronize()
+        outs.append(torch.stack(rows))
+    assert torch.equal(outs[0], outs[1])
