@@ -69,7 +69,7 @@ class So100VecEnv(_VecEnvBase):
     metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
 
     def __init__(self, env_id="Env01-v1", num_envs=4096, device=None, flags=F_REFERENCE, seed=0, env_id_offset=0,
-                 solver_iters=2, contact_iters=6, max_episode_steps=None, stagger_episodes=False, full_infos=True):
+                 solver_iters=2, contact_iters=6, max_episode_steps=None, stagger_episodes=False, full_infos=False):
         self.env_id = env_id
         self.kind = kind_from_id(env_id) if isinstance(env_id, str) else int(env_id)
         obs_space, act_space = make_spaces(self.kind)
@@ -81,6 +81,12 @@ class So100VecEnv(_VecEnvBase):
         self._stagger = stagger_episodes
         self._actions = torch.zeros(num_envs, 6, dtype=torch.float32, device=self.device)
         self._infos = [{} for _ in range(num_envs)]
+        # pinned host staging: one batch of async D2H copies + ONE stream sync per step_wait
+        od = self.sim.obs_dim
+        self._h_obs = torch.empty(num_envs, od, dtype=torch.float32, pin_memory=True)
+        self._h_rew = torch.empty(num_envs, dtype=torch.float32, pin_memory=True)
+        self._h_done = torch.empty(num_envs, dtype=torch.uint8, pin_memory=True)
+        self._h_trunc = torch.empty(num_envs, dtype=torch.uint8, pin_memory=True)
         self._dirty = []                                # infos filled on the previous step (cleared lazily)
         self._t0 = time.time()
         self.spec = type("Spec", (), {"id": K.ENV_IDS[self.kind], "max_episode_steps": self.sim.cfg.max_episode_steps,
@@ -109,14 +115,18 @@ class So100VecEnv(_VecEnvBase):
 
     def step_wait(self):
         obs, rew, done, trunc = self.sim.step(self._actions)
-        obs_h = obs.cpu().numpy(); rew_h = rew.cpu().numpy()
-        done_h = done.cpu().numpy().astype(bool)
+        self._h_obs.copy_(obs, non_blocking=True); self._h_rew.copy_(rew, non_blocking=True)
+        self._h_done.copy_(done, non_blocking=True); self._h_trunc.copy_(trunc, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        # fresh arrays every step: SB3 keeps `_last_obs` alive across the next env.step()
+        obs_h = self._h_obs.numpy().copy(); rew_h = self._h_rew.numpy().copy()
+        done_h = self._h_done.numpy().astype(bool)
         for i in self._dirty:
             self._infos[i] = {}
         self._dirty = []
         if done_h.any():
             idx = np.nonzero(done_h)[0]
-            trunc_h = trunc.cpu().numpy().astype(bool)
+            trunc_h = self._h_trunc.numpy().astype(bool)
             tobs = self.sim.terminal_obs[torch.as_tensor(idx, device=self.device)].cpu().numpy()
             ep_r = self.sim.ep_return.cpu().numpy(); ep_l = self.sim.ep_length.cpu().numpy()
             t = round(time.time() - self._t0, 6)
@@ -124,7 +134,7 @@ class So100VecEnv(_VecEnvBase):
                 self._infos[i] = {"terminal_observation": tobs[j], "TimeLimit.truncated": bool(trunc_h[i]),
                                   "episode": {"r": float(ep_r[i]), "l": int(ep_l[i]), "t": t}}
             self._dirty = list(idx)
-        if self.full_infos:
+        if self.full_infos:                             # SB3 itself reads infos with .get(..., False); only for strict consumers
             for i in range(self.num_envs):
                 self._infos[i].setdefault("TimeLimit.truncated", False)
         return obs_h, rew_h, done_h, self._infos
