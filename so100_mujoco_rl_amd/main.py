@@ -1,0 +1,183 @@
+"""Experiment driver with the reference's CLI surface (ref: /root/reference/src/so100_mujoco_rl/main.py:241-284):
+
+    python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] train  -e Env01-v1 [--envs 4096] [--iters N]
+    python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] test   -e Env01-v1 [--show-io] [--show-i]
+    python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] record -e Env01-v1
+
+Same directory layout (models/ logs/ movies/), default model path models/{env}_{algo}/best_model.*, reward thresholds
+(6000 / 8000, ref: __init__.py:9,16) and checkpoint naming ({env}_{algo}_cp_*, ref: main.py:227-232).  Differences, all
+forced by the environment being a batched GPU simulator: N envs instead of 1; the learner is stable-baselines3 when it
+is importable and the built-in PPO (ppo.py, SB3-compatible state_dict) otherwise; `record` writes a state trajectory
+(.npz) because there is no rasteriser (viewer / video are out of scope).
+"""
+import logging
+import os
+import time
+
+import click
+import numpy as np
+import torch
+
+from . import constants as K
+from .collector import RolloutCollector
+from .lib import F_REFERENCE
+from .ppo import PPO, ActorCritic
+from .vec_env import So100VecEnv, kind_from_id
+
+logging.basicConfig(level=logging.INFO, format="%(message)s")
+logger = logging.getLogger("so100")
+
+MODEL_DIR, LOG_DIR, RECORDING_DIR = "models", "logs", "movies"          # ref: main.py:28-30
+
+
+def _have_sb3():
+    try:
+        import stable_baselines3  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def _default_model_path(environment, algorithm):
+    return os.path.join(MODEL_DIR, f"{environment}_{algorithm}", "best_model.zip" if _have_sb3() else "best_model.pt")
+
+
+def _load_native(path, obs_dim, device):
+    net = ActorCritic(obs_dim).to(device)
+    net.load_state_dict(torch.load(path, map_location=device, weights_only=True))
+    return net
+
+
+@click.group()
+@click.option("-a", "--algorithm", required=True, type=str, default="PPO", help="algorithm (PPO natively; any Stable-Baselines3 name when SB3 is installed)")
+@click.option("-m", "--model", default=None, type=click.Path(exists=False), help="Path to model file")
+@click.pass_context
+def cli(ctx, algorithm, model):
+    if not _have_sb3() and algorithm != "PPO":
+        raise RuntimeError(f"algorithm {algorithm} needs stable-baselines3, which is not installed; the built-in learner is PPO")
+    ctx.ensure_object(dict)
+    ctx.obj["ALGORITHM_NAME"] = algorithm
+    ctx.obj["MODEL_PATH"] = model
+    for d in (MODEL_DIR, LOG_DIR, RECORDING_DIR):
+        os.makedirs(d, exist_ok=True)
+
+
+@cli.command(name="train", help="Train a model with a given environment")
+@click.option("-e", "--environment", required=True, type=str, help="id of the environment (eg; Env01-v1)")
+@click.option("--envs", default=4096, type=int, help="envs stepped in parallel on the GPU")
+@click.option("--iters", default=0, type=int, help="PPO updates (0 = until the reward threshold / no improvement)")
+@click.option("--seed", default=0, type=int)
+@click.pass_context
+def train(ctx, environment, envs, iters, seed):
+    algorithm = ctx.obj["ALGORITHM_NAME"]
+    kind = kind_from_id(environment)
+    env = So100VecEnv(environment, envs, flags=F_REFERENCE, seed=seed, stagger_episodes=True)
+    save_dir = os.path.join(MODEL_DIR, f"{environment}_{algorithm}")
+    os.makedirs(save_dir, exist_ok=True)
+    logger.info("Starting training process"); logger.info(f"Algorithm: {algorithm}"); logger.info(f"Environment: {environment} x {envs}")
+    if _have_sb3():                                          # unchanged SB3 learner over the batched VecEnv (ref: main.py:199-238)
+        import stable_baselines3
+        from stable_baselines3.common.callbacks import CheckpointCallback
+        cls = getattr(stable_baselines3, algorithm)
+        model_file = ctx.obj["MODEL_PATH"]
+        model = cls.load(model_file, env=env, tensorboard_log=LOG_DIR) if model_file else cls("MlpPolicy", env, verbose=1, device="cuda", tensorboard_log=LOG_DIR)
+        cb = CheckpointCallback(save_freq=max(1, 40000 // envs), save_path=save_dir, name_prefix=f"{environment}_{algorithm}_cp_", verbose=2)
+        model.learn(total_timesteps=int(1e10) if iters == 0 else iters * 64 * envs, tb_log_name=f"{environment}_{algorithm}", callback=cb)
+        model.save(os.path.join(save_dir, "best_model"))
+        return
+    learner = PPO(env.sim.obs_dim, env.device, seed=seed)
+    if ctx.obj["MODEL_PATH"]:
+        if not os.path.isfile(ctx.obj["MODEL_PATH"]):
+            raise RuntimeError(f"Model file {ctx.obj['MODEL_PATH']} does not exist")
+        learner.net.load_state_dict(torch.load(ctx.obj["MODEL_PATH"], map_location=env.device, weights_only=True))
+        logger.info(f"Model: starting with {ctx.obj['MODEL_PATH']}")
+    else:
+        logger.info("Model: starting with new model")
+    col = RolloutCollector(env, learner.net.state_dict(), T=64)
+    threshold = K.REWARD_THRESHOLD[kind]                     # StopTrainingOnRewardThreshold (ref: main.py:211)
+    best, since_best, steps, t0, it = -float("inf"), 0, 0, time.time(), 0
+    ep_sum = ep_cnt = 0.0
+    while True:
+        b = col.collect()
+        done = (b["dones"] > 0).any(0)                       # ep_return holds the return of the latest episode that ended in the chunk
+        if done.any():
+            ep_sum += env.sim.ep_return[done].sum().item(); ep_cnt += int(done.sum().item())
+        stats = learner.update(b)
+        col.load_policy(learner.net.state_dict())
+        steps += b["rewards"].numel(); it += 1
+        if it % 10 == 0:
+            mean_ep = ep_sum / ep_cnt if ep_cnt else float("nan")
+            logger.info(f"iter {it:5d}  timesteps {steps/1e6:8.1f} M  reward/step {stats['mean_reward']:+.4f}  ep_rew_mean {mean_ep:9.2f}  "
+                        f"value_loss {stats['value_loss']:.4f}  fps {steps/(time.time()-t0)/1e6:.1f} M")
+            score = stats["mean_reward"]
+            if score > best:
+                best, since_best = score, 0
+                torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt"))
+            else:
+                since_best += 1
+            if ep_cnt and mean_ep >= threshold:
+                logger.info(f"Stopping training: mean episode reward {mean_ep:.1f} reached the threshold {threshold}"); break
+            ep_sum = ep_cnt = 0.0
+        if it % 40 == 0:                                     # CheckpointCallback (ref: main.py:227-232)
+            torch.save(learner.net.state_dict(), os.path.join(save_dir, f"{environment}_{algorithm}_cp__{steps}_steps.pt"))
+        if (iters and it >= iters) or since_best >= 50:
+            break
+    torch.save(learner.net.state_dict(), os.path.join(save_dir, "last_model.pt"))
+    logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best reward/step {best:+.4f}; models in {save_dir}")
+
+
+def _rollout_policy(environment, algorithm, model_file, n, steps, show_io, show_i, record_path=None):
+    env = So100VecEnv(environment, n, flags=F_REFERENCE, seed=1)
+    if model_file is None:
+        model_file = _default_model_path(environment, algorithm)
+    if not os.path.isfile(model_file):
+        raise RuntimeError(f"Could not open model file: {model_file}")
+    logger.info(f"Algorithm: {algorithm}"); logger.info(f"Environment: {environment}"); logger.info(f"Model: {model_file}")
+    if model_file.endswith(".zip"):
+        import stable_baselines3
+        policy = getattr(stable_baselines3, algorithm).load(model_file, device="cuda").policy
+        act_fn = lambda o: policy._predict(o, deterministic=True)
+    else:
+        net = _load_native(model_file, env.sim.obs_dim, env.device)
+        act_fn = net.mean_action
+    obs = env.reset_tensor()
+    total = 0.0; traj = []
+    with torch.no_grad():
+        for t in range(steps):
+            a = act_fn(obs).clamp(-1, 1).contiguous()
+            if (show_io or show_i) and t % 30 == 0:           # ref: main.py:110-113
+                logger.info(str(obs[0].tolist() + (a[0].tolist() if show_io else [])) + ("," if show_i else ""))
+            if record_path is not None:
+                q, v = env.sim.get_state()
+                traj.append(np.concatenate([q[:, 0].cpu().numpy(), v[:, 0].cpu().numpy(), obs[0].cpu().numpy(), a[0].cpu().numpy()]))
+            obs, r, d, tr = env.step_tensor(a)
+            total += r.mean().item()
+    logger.info(f"mean reward/step over {steps} steps x {n} envs: {total/steps:+.4f}")
+    if record_path is not None:
+        np.savez(record_path, trajectory=np.stack(traj), layout="qpos[13] qvel[12] obs action[6] per step, env 0")
+        logger.info(f"wrote {record_path} (state trajectory; no rasteriser in this build)")
+    return total / steps
+
+
+@cli.command(name="test", help="Test the current model")
+@click.option("-e", "--environment", required=True, type=str)
+@click.option("--show-io", is_flag=True, default=False, help="log model inputs and outputs")
+@click.option("--show-i", is_flag=True, default=False, help="log model inputs in Python array syntax")
+@click.option("--envs", default=256, type=int)
+@click.option("--steps", default=1000, type=int)
+@click.pass_context
+def test(ctx, environment, show_io, show_i, envs, steps):
+    logger.info("Starting test simulation")
+    _rollout_policy(environment, ctx.obj["ALGORITHM_NAME"], ctx.obj["MODEL_PATH"], envs, steps, show_io, show_i)
+
+
+@cli.command(name="record", help="Record a model with a given environment")
+@click.option("-e", "--environment", required=True, type=str)
+@click.pass_context
+def record(ctx, environment):
+    path = os.path.join(RECORDING_DIR, f"{environment}_{ctx.obj['ALGORITHM_NAME']}.npz")
+    _rollout_policy(environment, ctx.obj["ALGORITHM_NAME"], ctx.obj["MODEL_PATH"], 1, 3000, False, False, record_path=path)   # 3000 steps, ref: main.py:161
+
+
+if __name__ == "__main__":
+    cli(obj={})

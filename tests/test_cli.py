@@ -1,0 +1,55 @@
+"""The experiment driver (so100_mujoco_rl_amd/main.py) mirrors the reference CLI (ref: main.py:241-284):
+`-a ALGO [-m MODEL] train|test|record -e ENV_ID`, directories models/ logs/ movies/."""
+import os
+
+import numpy as np
+import pytest
+from click.testing import CliRunner
+
+from so100_mujoco_rl_amd import main as drv
+
+
+def test_cli_surface(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    r = CliRunner().invoke(drv.cli, ["--help"])
+    assert r.exit_code == 0
+    for word in ("train", "test", "record", "--algorithm", "--model"):
+        assert word in r.output
+    for cmd in ("train", "test", "record"):
+        r = CliRunner().invoke(drv.cli, ["-a", "PPO", cmd, "--help"])
+        assert r.exit_code == 0 and "--environment" in r.output
+        assert all(os.path.isdir(d) for d in ("models", "logs", "movies"))     # ref: main.py:33-40
+    r = CliRunner().invoke(drv.cli, ["-a", "PPO", "test", "--help"])
+    assert "--show-io" in r.output and "--show-i" in r.output
+
+
+def test_cli_errors(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    if not drv._have_sb3():
+        r = CliRunner().invoke(drv.cli, ["-a", "SAC", "train", "-e", "Env01-v1"])
+        assert r.exit_code != 0 and "stable-baselines3" in str(r.exception)
+    r = CliRunner().invoke(drv.cli, ["-a", "PPO", "train"])                     # -e is required
+    assert r.exit_code == 2
+    assert drv._default_model_path("Env01-v1", "PPO").startswith(os.path.join("models", "Env01-v1_PPO", "best_model"))
+
+
+@pytest.mark.gpu
+def test_cli_train_test_record(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    run = CliRunner()
+    r = run.invoke(drv.cli, ["-a", "PPO", "train", "-e", "Env01-v1", "--envs", "1024", "--iters", "40"], catch_exceptions=False)
+    assert r.exit_code == 0
+    d = tmp_path / "models" / "Env01-v1_PPO"
+    assert (d / "best_model.pt").is_file() and (d / "last_model.pt").is_file()
+    assert any(f.name.startswith("Env01-v1_PPO_cp_") for f in d.iterdir())
+    r = run.invoke(drv.cli, ["-a", "PPO", "test", "-e", "Env01-v1", "--envs", "64", "--steps", "64", "--show-io"], catch_exceptions=False)
+    assert r.exit_code == 0
+    r = run.invoke(drv.cli, ["-a", "PPO", "-m", str(d / "last_model.pt"), "train", "-e", "Env01-v1", "--envs", "256", "--iters", "2"],
+                   catch_exceptions=False)                                       # resume from a checkpoint
+    assert r.exit_code == 0
+    r = run.invoke(drv.cli, ["-a", "PPO", "-m", str(tmp_path / "nope.pt"), "test", "-e", "Env01-v1"])
+    assert r.exit_code != 0 and "Could not open model file" in str(r.exception)
+    r = run.invoke(drv.cli, ["-a", "PPO", "record", "-e", "Env01-v1"], catch_exceptions=False)
+    assert r.exit_code == 0
+    traj = np.load(tmp_path / "movies" / "Env01-v1_PPO.npz")["trajectory"]
+    assert traj.shape == (3000, 13 + 12 + 15 + 6) and np.isfinite(traj).all()
