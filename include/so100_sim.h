@@ -28,12 +28,13 @@ extern "C" {
 
 #define SO100_ABI_VERSION 1
 
-/* env kinds == the reference's registered ids Env01-v1 .. Env05-v1 (ref: __init__.py:5-38) */
+/* env kinds == the reference's registered ids Env01-v1 .. Env06-v1 (ref: __init__.py:5-45) */
 #define SO100_ENV01 1   /* ref: envs/env01_v1.py  reach, random start pose              obs 15 */
 #define SO100_ENV02 2   /* ref: envs/env02_v1.py  reach + re-randomise on reach         obs 15 */
 #define SO100_ENV03 3   /* ref: envs/env03_v1.py  look-at, moving cube (analytic detector) obs 8 */
 #define SO100_ENV04 4   /* ref: envs/env04_v1.py  look-at, jumping cube (analytic detector) obs 8 */
 #define SO100_ENV05 5   /* ref: envs/env05_v1.py  look-at, analytic reprojection + noise  obs 8 */
+#define SO100_ENV06 6   /* ref: envs/env06_v1.py  reach + close the gripper (env_base_06.py) obs 15 */
 
 /* physics option flags (which MuJoCo constraint families are simulated) */
 #define SO100_F_FRICTIONLOSS 1u   /* joint friction loss 0.1 (model/so_arm100_camera.xml:32)        */
@@ -52,7 +53,7 @@ extern "C" {
 typedef struct so100_sim so100_sim;
 
 typedef struct {
-    int32_t  env_kind;            /* SO100_ENV01..05                                               */
+    int32_t  env_kind;            /* SO100_ENV01..06                                               */
     int32_t  num_envs;            /* N, any positive number                                        */
     int32_t  device;              /* HIP device ordinal                                            */
     uint32_t flags;               /* SO100_F_*                                                     */
@@ -133,6 +134,8 @@ int  so100_abi_version(void);
 int  so100_obs_dim(int32_t env_kind);                     /* ref: env_base_01.py:63-75 (15), env_base_02.py:56-69 (8) */
 int  so100_num_state_fields(void);                        /* rows of the [field][N] state matrix */
 int  so100_state_field_index(const char* name);           /* e.g. "q0", "elapsed_steps"; -1 if unknown */
+const char* so100_state_field_name(int32_t field);        /* inverse of the above; NULL if out of range (used by the
+                                                             state save/restore wire format) */
 
 /* ref: gym.make(id) -> EnvNN.__init__ -> mujoco.MjModel.from_xml_path + MujocoEnv.__init__
  * (envs/env_base_01.py:35-51).  The model is compiled in (csrc/so100_model_def.h). */

@@ -618,7 +618,8 @@ static const double SPACE_START[2][3] = { {-0.05, -0.4, 0.01}, {0.05, -0.3, 0.01
 static const double SPACE_END_03[2][3] = { {-0.35, -0.45, 0.01}, {0.35, -0.25, 0.01} }; /* env03_v1.py:17-20 */
 static const double SPACE_END_05[2][3] = { {-0.45, -0.45, 0.01}, {0.45, -0.25, 0.5} };  /* env05_v1.py:17-20 */
 
-int so100o_obs_dim(int kind) { return kind <= 2 ? 15 : 8; }
+static int reach_kind(int kind) { return kind <= 2 || kind == 6; }   /* obs 15, env_base_01.py / env_base_06.py */
+int so100o_obs_dim(int kind) { return reach_kind(kind) ? 15 : 8; }
 
 double so100o_joint_penalty(double a, double lo, double hi) {          /* env_base_01.py:153-163 */
     double penalty = 0.0;
@@ -700,7 +701,7 @@ void so100o_env_init(const so100o_model* m, so100o_env* e, int kind, unsigned fl
     e->max_episode_steps = kind == 1 ? 4000 : 6000;           /* so100_mujoco_rl/__init__.py:5-38 */
     e->seed = seed; e->env_id = env_id;
     so100o_reset_data(m, &e->d);
-    if (kind >= 3) {                                          /* env_base_02.py:32,51 */
+    if (!reach_kind(kind)) {                                  /* env_base_02.py:32,51 */
         set_initial_values_03(e);
         for (int i = 0; i < 3; i++) e->d.qpos[6 + i] = e->block_target[i];
     }
@@ -725,12 +726,12 @@ static void obs_cam(const so100o_env* e, const float* u8, int noise, float* obs)
 }
 
 static void set_random_block_position(so100o_env* e, double dlo, const float* u) {
-    /* env01_v1.py:45-52 (dlo=0.18), env02_v1.py:52-68 (dlo=0.22); u[1] is the discarded draw */
+    /* env01_v1.py:45-52 (dlo=0.18), env02_v1.py:52-68 and env06_v1.py:52-69 (dlo=0.22); u[1] is the discarded draw */
     double dist = dlo + (0.42 - dlo)*(double)u[0];
     double theta = -0.5*PI + (-0.25*PI + (0.5*PI)*(double)u[2]);
     double p[3] = { dist*cos(theta), dist*sin(theta), 0.0 };
     memcpy(e->d.qpos + 6, p, sizeof p);
-    if (e->kind == 2) {
+    if (e->kind == 2 || e->kind == 6) {
         if (!e->have_last_block_pos) { memcpy(e->last_block_pos, p, sizeof p); e->have_last_block_pos = 1; }
         else memcpy(e->last_block_pos, e->block_pos, sizeof p);
         memcpy(e->block_pos, p, sizeof p); e->have_block_pos = 1;
@@ -750,7 +751,7 @@ void so100o_env_reset(const so100o_model* m, so100o_env* e, const float* inject,
         for (int i = 0; i < 5; i++) e->d.qpos[i] = SO100_VALID_START_POSITIONS[idx][i];  /* Jaw skipped */
         obs_base(e, obs);
     } break;
-    case 2:                                                   /* env02_v1.py:70-81 */
+    case 2: case 6:                                           /* env02_v1.py:70-81, env06_v1.py:71-82 */
         set_random_block_position(e, 0.22, u);
         for (int i = 0; i < 6; i++) e->d.qpos[i] = REST_POSITION[i];
         obs_base(e, obs);
@@ -778,16 +779,21 @@ void so100o_env_step(const so100o_model* m, so100o_env* e, const float* a, const
     double reward = 0.0; int term = 0;
     const int od = so100o_obs_dim(e->kind);
 
-    if (e->kind <= 2) {
-        /* env01_v1.py:15-37 / env02_v1.py:18-50 */
+    if (reach_kind(e->kind)) {
+        /* env01_v1.py:15-37 / env02_v1.py:18-50 / env06_v1.py:18-50 */
         double ee[3]; so100o_end_effector(d->xpos[6], d->xmat[6], ee);
         reward = so100o_reward_base(m, d->qpos, d->xpos[CUBE], ee, d->xpos[5], e->has_prev);
         e->has_prev = 1;
         for (int i = 0; i < 6; i++)      /* np.float64 + (np.float32 * weak python float) */
             d->ctrl[i] = d->qpos[i] + (double)(float)((float)a[i] * (float)JOINT_STEP_SCALE_F32);
-        if (e->kind == 2 && norm3d(d->xpos[CUBE], ee) < 0.03) {
+        if ((e->kind == 2 || e->kind == 6) && norm3d(d->xpos[CUBE], ee) < 0.03) {
+            if (e->kind == 6) {                                   /* gripper term: env_base_06.py:149-162, 253-256 */
+                double jn = (d->qpos[5] + 0.2) / 2.2;
+                jn = jn < 0.0 ? 0.0 : jn > 1.0 ? 1.0 : jn;
+                reward += 100.0 * (1.0 / (1.0 + exp(-10 * (jn - 0.3))));
+            }
             reward += norm3d(e->block_pos, e->last_block_pos) * 20;
-            set_random_block_position(e, 0.22, u);
+            if (e->kind == 2) set_random_block_position(e, 0.22, u);   /* commented out in env06_v1.py:36 */
         }
         so100o_step(m, d, e->flags, e->iters, e->frame_skip);
         obs_base(e, obs);

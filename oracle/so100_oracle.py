@@ -126,7 +126,7 @@ def arr(cfield):
 
 
 class OracleEnv:
-    """One reference-semantics env (kind 1..5) on the CPU."""
+    """One reference-semantics env (kind 1..6) on the CPU."""
 
     def __init__(self, kind, flags=F_FRICTIONLOSS | F_LIMITS | F_FLOOR, iters=0, seed=0, env_id=0):
         self.L = lib(); self.m = model(); self.e = Env()

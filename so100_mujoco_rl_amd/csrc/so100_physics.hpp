@@ -34,6 +34,7 @@ template <typename T> SO100_HD T tabs(T a) { return a < T(0) ? -a : a; }
 
 SO100_HD float  tsqrt(float x)  { return __builtin_sqrtf(x); }
 SO100_HD double tsqrt(double x) { return __builtin_sqrt(x); }
+SO100_HD float  texp(float x)   { return __builtin_expf(x); }
 // reciprocal: on the device one v_rcp_f32 (1 ulp) plus a Newton step instead of the ~10-instruction IEEE division
 SO100_HD float trcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
             if (wave == 0) {
                 e.nsub += p.frame_skip;
                 TaskPoses<float> P;
-                task_poses<float>(A.s, A.c, KIND >= 3, P);
+                task_poses<float>(A.s, A.c, !reach_kind<KIND>(), P);
                 float obs[OD], tobs[OD]; bool term;
                 const float reward = env_step_post<KIND>(e, ctx, ustep, P, cstale, obs, term);
                 const StepResult r = env_step_finish<KIND>(e, reward, term, p, p.env_id_offset + (uint32_t)env, nullptr, start_tab, obs, tobs);

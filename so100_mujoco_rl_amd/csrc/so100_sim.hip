@@ -67,7 +67,7 @@ struct StepPtrs {
 // batches need (1 M envs: 2 waves/SIMD 2.3 G env-steps/s, 1 wave/SIMD 1.5 G); the constrained variants and the
 // look-at envs (more task state) need > 256 and would spill.
 template <int KIND, int FL>
-__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && KIND <= 2) ? 2 : 1)) so100_step_fused(SimParams p, StepPtrs io) {
+__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_kind<KIND>()) ? 2 : 1)) so100_step_fused(SimParams p, StepPtrs io) {
     const int env = blockIdx.x*WG + threadIdx.x;
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
@@ -191,25 +191,26 @@ template <int KIND> int launch_init(so100_sim* s) {
     return 0;
 }
 #define DISPATCH_KIND(kind, call) \
-    ((kind) == 1 ? call<1> : (kind) == 2 ? call<2> : (kind) == 3 ? call<3> : (kind) == 4 ? call<4> : call<5>)
+    ((kind) == 1 ? call<1> : (kind) == 2 ? call<2> : (kind) == 3 ? call<3> : (kind) == 4 ? call<4> : (kind) == 5 ? call<5> : call<6>)
 }  // namespace
 
 extern "C" {
 
 int so100_abi_version(void) { return SO100_ABI_VERSION; }
-int so100_obs_dim(int32_t kind) { return (kind >= 1 && kind <= 2) ? 15 : (kind >= 3 && kind <= 5) ? 8 : -1; }
+int so100_obs_dim(int32_t kind) { return (kind == 1 || kind == 2 || kind == 6) ? 15 : (kind >= 3 && kind <= 5) ? 8 : -1; }
 int so100_num_state_fields(void) { return SF_COUNT; }
 int so100_state_field_index(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < SF_COUNT; i++) if (strcmp(kFieldNames[i], name) == 0) return i;
     return -1;
 }
+const char* so100_state_field_name(int32_t field) { return (field >= 0 && field < SF_COUNT) ? kFieldNames[field] : nullptr; }
 const char* so100_last_error(void) { return g_err; }
 
 int so100_create(const so100_config* cfg, so100_sim** out) {
     if (!cfg || !out) return fail(SO100_E_INVALID, "so100_create: null argument%s");
     *out = nullptr;
-    if (cfg->env_kind < 1 || cfg->env_kind > 5) return fail(SO100_E_INVALID, "so100_create: env_kind must be 1..5%s");
+    if (cfg->env_kind < 1 || cfg->env_kind > 6) return fail(SO100_E_INVALID, "so100_create: env_kind must be 1..6%s");
     if (cfg->num_envs < 1) return fail(SO100_E_INVALID, "so100_create: num_envs must be >= 1%s");
     if (cfg->solver_iters < 1 || cfg->solver_iters > 64) return fail(SO100_E_INVALID, "so100_create: solver_iters must be in 1..64%s");
     if (cfg->contact_iters < 1 || cfg->contact_iters > 64) return fail(SO100_E_INVALID, "so100_create: contact_iters must be in 1..64%s");
@@ -290,7 +291,7 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
     static const int nw = []{ const char* e = getenv("SO100_POLICY_WAVES"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
 #define SO100_LAUNCH_POLICY(OD, NW) hipLaunchKernelGGL((so100_policy_forward_kernel<OD, NW>), grid, dim3(64*NW), 0, (hipStream_t)stream, \
         s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter)
-    if (s->cfg.env_kind <= 2) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
+    if (so100_obs_dim(s->cfg.env_kind) == 15) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
     else                      { if (nw == 4) SO100_LAUNCH_POLICY(8, 4);  else if (nw == 8) SO100_LAUNCH_POLICY(8, 8);  else SO100_LAUNCH_POLICY(8, 16); }
 #undef SO100_LAUNCH_POLICY
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
@@ -315,7 +316,7 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
 #define SO100_RL_FL(KIND, NW) do { if (s->prm.flags == SO100_F_CUBE_PINNED) SO100_RL(KIND, SO100_F_CUBE_PINNED, NW); \
         else if (s->prm.flags == SO100_F_REFERENCE) SO100_RL(KIND, SO100_F_REFERENCE, NW); else SO100_RL(KIND, -1, NW); } while (0)
 #define SO100_RL_KIND(NW) switch (s->cfg.env_kind) { case 1: SO100_RL_FL(1, NW); break; case 2: SO100_RL_FL(2, NW); break; \
-        case 3: SO100_RL_FL(3, NW); break; case 4: SO100_RL_FL(4, NW); break; default: SO100_RL_FL(5, NW); }
+        case 3: SO100_RL_FL(3, NW); break; case 4: SO100_RL_FL(4, NW); break; case 5: SO100_RL_FL(5, NW); break; default: SO100_RL_FL(6, NW); }
     SO100_RL_KIND(4)
 #undef SO100_RL_KIND
 #undef SO100_RL_FL

@@ -43,7 +43,7 @@ struct EnvState {
 };
 
 // The [field][N] state matrix.  X(name, member, kind, group): kind f = float, i = int32;
-// group 0 = all env kinds, 1 = Env01/02, 2 = Env02, 3 = Env03-05.
+// group 0 = all env kinds, 1 = Env01/02/06 (reach family), 2 = Env02/06 (block memory), 3 = Env03-05 (look-at family).
 #define SO100_STATE_FIELDS(X) \
     X(q0, q[0], f, 0) X(q1, q[1], f, 0) X(q2, q[2], f, 0) X(q3, q[3], f, 0) X(q4, q[4], f, 0) X(q5, q[5], f, 0) \
     X(cube_x, cube.pos[0], f, 0) X(cube_y, cube.pos[1], f, 0) X(cube_z, cube.pos[2], f, 0) \
@@ -74,10 +74,12 @@ enum StateField : int {
 };
 constexpr int SF_QPOS0 = SF_q0, SF_QVEL0 = SF_v0;       // 13 qpos rows then 12 qvel rows, contiguous
 
+template <int KIND> SO100_HD constexpr bool reach_kind() { return KIND <= 2 || KIND == 6; }    // obs 15, reward env_base_01/06
+template <int KIND> SO100_HD constexpr bool block_kind() { return KIND == 2 || KIND == 6; }    // block_pos / last_block_pos memory
 template <int KIND> SO100_HD constexpr bool uses_group(int g) {
-    return g == 0 || (g == 1 && KIND <= 2) || (g == 2 && KIND == 2) || (g == 3 && KIND >= 3);
+    return g == 0 || (g == 1 && reach_kind<KIND>()) || (g == 2 && block_kind<KIND>()) || (g == 3 && !reach_kind<KIND>());
 }
-template <int KIND> SO100_HD constexpr int obs_dim() { return KIND <= 2 ? 15 : 8; }
+template <int KIND> SO100_HD constexpr int obs_dim() { return reach_kind<KIND>() ? 15 : 8; }
 
 // ---- constants of the task layer --------------------------------------------------------------------
 #define SO100_PI_F 3.14159265358979323846f
@@ -164,14 +166,14 @@ SO100_HD bool project(const float cam_pos[3], const float cam_mat[9], const floa
     return true;
 }
 
-SO100_HD void set_random_block_position(EnvState& e, int kind, float dlo, const float u[8]) {
-    // ref: env01_v1.py:45-52 (dlo 0.18), env02_v1.py:52-68 (dlo 0.22); u[1] is the discarded draw
+SO100_HD void set_random_block_position(EnvState& e, bool remember, float dlo, const float u[8]) {
+    // ref: env01_v1.py:45-52 (dlo 0.18), env02_v1.py:52-68 and env06_v1.py:52-69 (dlo 0.22, remember); u[1] is the discarded draw
     const float dist = dlo + (0.42f - dlo)*u[0];
     const float theta = -0.5f*SO100_PI_F + (-0.25f*SO100_PI_F + (0.5f*SO100_PI_F)*u[2]);
     float s, c; tsincos<float>(theta, s, c);
     const float p[3] = { dist*c, dist*s, 0.0f };
     e.cube.pos[0] = p[0]; e.cube.pos[1] = p[1]; e.cube.pos[2] = p[2];
-    if (kind == 2) {
+    if (remember) {
         if (!(e.bits & B_HAVE_LAST_BLOCK)) { e.lbp[0] = p[0]; e.lbp[1] = p[1]; e.lbp[2] = p[2]; e.bits |= B_HAVE_LAST_BLOCK; }
         else { e.lbp[0] = e.bp[0]; e.lbp[1] = e.bp[1]; e.lbp[2] = e.bp[2]; }
         e.bp[0] = p[0]; e.bp[1] = p[1]; e.bp[2] = p[2]; e.bits |= B_HAVE_BLOCK;
@@ -193,7 +195,7 @@ template <int KIND> SO100_HD void set_initial_values_03(EnvState& e) {     // re
 template <int KIND> SO100_HD void env_init(EnvState& e) {
     e = EnvState{};
     e.cube.quat[0] = 1.0f;
-    if (KIND >= 3) {                                                       // ref: env_base_02.py:32,51
+    if (!reach_kind<KIND>()) {                                             // ref: env_base_02.py:32,51
         set_initial_values_03<KIND>(e);
         e.cube.pos[0] = e.tgt[0]; e.cube.pos[1] = e.tgt[1]; e.cube.pos[2] = e.tgt[2];
     }
@@ -210,12 +212,12 @@ template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const
     e.nsub = 0; e.bits &= ~B_ANTIGRAV;
     e.elapsed = 0; e.epret = 0.0f; e.eplen = 0;
     if (KIND == 1) {                                                       // ref: env01_v1.py:39-63
-        set_random_block_position(e, 1, 0.18f, u);
+        set_random_block_position(e, false, 0.18f, u);
         int idx = (int)(u[3]*36.0f); idx = idx > 35 ? 35 : idx;
 #pragma unroll
         for (int i = 0; i < 5; i++) e.q[i] = start_tab[6*idx + i];                             // Jaw skipped (:58-59)
-    } else if (KIND == 2) {                                                // ref: env02_v1.py:70-81
-        set_random_block_position(e, 2, 0.22f, u);
+    } else if (block_kind<KIND>()) {                                       // ref: env02_v1.py:70-81, env06_v1.py:71-82
+        set_random_block_position(e, true, 0.22f, u);
 #pragma unroll
         for (int i = 0; i < 6; i++) e.q[i] = REST_POSITION[i];
     } else {                                                               // ref: env03_v1.py:203-215
@@ -224,7 +226,7 @@ template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const
 #pragma unroll
         for (int i = 0; i < 6; i++) e.q[i] = START_POSITION[i];
     }
-    if (KIND <= 2) {                                                       // ref: env_base_01.py:241-270, all poses zero (Q1)
+    if (reach_kind<KIND>()) {                                              // ref: env_base_01.py:241-270, all poses zero (Q1)
 #pragma unroll
         for (int i = 0; i < 6; i++) obs[i] = e.q[i];
 #pragma unroll
@@ -264,18 +266,22 @@ struct StepCtx {
 };
 
 template <int KIND> SO100_HD void env_step_pre(EnvState& e, const float a[6], const float u[8], const SimParams& p, StepCtx& c) {
-    if (KIND <= 2) {
-        // ref: env01_v1.py:15-37 / env02_v1.py:18-50
+    if (reach_kind<KIND>()) {
+        // ref: env01_v1.py:15-37 / env02_v1.py:18-50 / env06_v1.py:18-50
         c.reward = reward_base(e.q, e.cx, e.ee, e.wrist_z, (e.bits & B_HAS_PREV) != 0);
         e.bits |= B_HAS_PREV;
 #pragma unroll
         for (int i = 0; i < 6; i++) c.ctrl[i] = e.q[i] + a[i]*JOINT_STEP_SCALE;
-        if (KIND == 2) {
+        if (block_kind<KIND>()) {
             const float dx = e.cx[0] - e.ee[0], dy = e.cx[1] - e.ee[1], dz = e.cx[2] - e.ee[2];
             if (tsqrt(dx*dx + dy*dy + dz*dz) < 0.03f) {
+                if (KIND == 6) {                                           // gripper term, ref: env_base_06.py:149-162, 253-256
+                    const float jn = tmin(tmax((e.q[5] + 0.2f)*(1.0f/2.2f), 0.0f), 1.0f);
+                    c.reward += 100.0f/(1.0f + texp(-10.0f*(jn - 0.3f)));
+                }
                 const float bx = e.bp[0] - e.lbp[0], by = e.bp[1] - e.lbp[1], bz = e.bp[2] - e.lbp[2];
                 c.reward += tsqrt(bx*bx + by*by + bz*bz)*20.0f;
-                set_random_block_position(e, 2, 0.22f, u);
+                if (KIND == 2) set_random_block_position(e, true, 0.22f, u);   // Env06 keeps the cube (env06_v1.py:36)
             }
         }
     } else {
@@ -325,7 +331,7 @@ template <int KIND> SO100_HD float env_step_post(EnvState& e, const StepCtx& c, 
                                                   const float cstale[3], float* obs, bool& term) {
     term = false;
     float reward;
-    if (KIND <= 2) {
+    if (reach_kind<KIND>()) {
         reward = c.reward;
         // stale poses -> persistent (read by the next step's reward) and -> obs; ref: env_base_01.py:118-127, 241-270
 #pragma unroll
@@ -396,7 +402,7 @@ template <int KIND> SO100_HD float env_step(EnvState& e, const float a[6], const
     env_step_pre<KIND>(e, a, u, p, c);
     TaskPoses<float> P;
     float cstale[3];
-    physics_substeps(e, c.ctrl, p, KIND >= 3, P, cstale);
+    physics_substeps(e, c.ctrl, p, !reach_kind<KIND>(), P, cstale);
     return env_step_post<KIND>(e, c, u, P, cstale, obs, term);
 }
 

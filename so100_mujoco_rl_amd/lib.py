@@ -8,12 +8,13 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
 import torch  # imported BEFORE the .so so that both bind to the same libamdhip64 (see csrc/Makefile)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libso100sim.so")
 
-ENV01, ENV02, ENV03, ENV04, ENV05 = 1, 2, 3, 4, 5
+ENV01, ENV02, ENV03, ENV04, ENV05, ENV06 = 1, 2, 3, 4, 5, 6
 F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR
 NINJECT = 16
@@ -59,7 +60,7 @@ class PolicyIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("obs_dev", "noise_dev", "act_env_dev", "act_raw_dev", "value_dev", "logp_dev", "rollout_row_dev")]
 
 
-EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_create",
+EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_state_field_name", "so100_create",
            "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
            "so100_set_field", "so100_last_error", "so100_policy_forward", "so100_rollout"]
 
@@ -87,6 +88,7 @@ def load():
         L = C.CDLL(LIB_PATH)
         L.so100_last_error.restype = C.c_char_p
         L.so100_state_field_index.argtypes = [C.c_char_p]
+        L.so100_state_field_name.argtypes = [C.c_int32]; L.so100_state_field_name.restype = C.c_char_p
         L.so100_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
         L.so100_destroy.argtypes = [C.c_void_p]
         L.so100_destroy.restype = None
@@ -129,7 +131,7 @@ class So100Sim:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         if max_episode_steps is None:
-            max_episode_steps = 4000 if env_kind == ENV01 else 6000       # ref: so100_mujoco_rl/__init__.py:5-38
+            max_episode_steps = 4000 if env_kind == ENV01 else 6000       # ref: so100_mujoco_rl/__init__.py:5-45
         self.cfg = Config(env_kind, num_envs, self.device.index, flags, solver_iters, contact_iters, frame_skip,
                           max_episode_steps, seed, env_id_offset, 0)
         h = C.c_void_p()
@@ -223,6 +225,33 @@ class So100Sim:
         if i < 0:
             raise So100Error(f"unknown state field {name!r}")
         return i
+
+    def field_names(self):
+        return [self.L.so100_state_field_name(i).decode() for i in range(self.L.so100_num_state_fields())]
+
+    # ---- sim checkpoint: the whole [field][N] state matrix as raw 32-bit words + the current
+    # observation, beside the learner's own checkpoint (ref: main.py:227-232 saves only the SB3 zip).  Resuming is
+    # bit exact: the Philox counters and the solver warm starts are rows of the matrix.
+    def save_state(self, path):
+        names = self.field_names()
+        words = torch.stack([self.get_field(n, dtype=torch.int32) for n in names]).cpu().numpy()
+        c = self.cfg
+        np.savez(path, words=words, names=np.array(names), obs=self.obs.cpu().numpy(),
+                 config=np.array([c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip,
+                                  c.max_episode_steps, c.seed, c.env_id_offset], dtype=np.int64))
+
+    def load_state(self, path):
+        with np.load(path, allow_pickle=False) as z:
+            words, names, obs, conf = z["words"], [str(n) for n in z["names"]], z["obs"], z["config"]
+        if int(conf[0]) != self.cfg.env_kind or int(conf[1]) != self.n:
+            raise So100Error(f"checkpoint is for env kind {int(conf[0])} x {int(conf[1])} envs, this sim is kind {self.cfg.env_kind} x {self.n}")
+        missing = set(self.field_names()) - set(names)
+        if missing:
+            raise So100Error(f"checkpoint lacks state fields {sorted(missing)}")
+        for row, n in zip(words, names):
+            if self.L.so100_state_field_index(n.encode()) >= 0:
+                self.set_field(n, torch.from_numpy(row).to(self.device))
+        self.obs.copy_(torch.from_numpy(obs))
 
     def get_field(self, name, dtype=torch.float32):
         out = torch.empty(self.n, dtype=dtype, device=self.device)

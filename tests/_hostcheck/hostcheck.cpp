@@ -68,7 +68,7 @@ template <int KIND> void env_stp(EnvState* e, const SimParams& p, const float* a
     *rew = r.reward; *done = r.done; *trunc = r.trunc_only;
 }
 }
-#define KSWITCH(kind, fn, ...) switch (kind) { case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; default: fn<5>(__VA_ARGS__); }
+#define KSWITCH(kind, fn, ...) switch (kind) { case 1: fn<1>(__VA_ARGS__); break; case 2: fn<2>(__VA_ARGS__); break; case 3: fn<3>(__VA_ARGS__); break; case 4: fn<4>(__VA_ARGS__); break; case 5: fn<5>(__VA_ARGS__); break; default: fn<6>(__VA_ARGS__); }
 extern "C" {
 void* hc_env_new(int kind) { EnvState* e = new EnvState; KSWITCH(kind, env_new, e); return e; }
 void hc_env_free(void* e) { delete (EnvState*)e; }

@@ -3,7 +3,7 @@
 Run (build container only; /root/reference does not exist on the GPU box):
     python3 -B tests/golden/make_golden.py
 
-How: the reference's env classes (env01_v1.Env01, env02_v1.Env02, env05_v1.Env05) are imported
+How: the reference's env classes (env01_v1.Env01, env02_v1.Env02, env05_v1.Env05, env06_v1.Env06) are imported
 unmodified from /root/reference/src with the third-party modules that are not installed here
 (mujoco, gymnasium, glfw, cv2, ultralytics, PIL) replaced by stubs in sys.modules:
   * `MjData` is a thin named-accessor view over the oracle's fp64 `so100o_data` struct,
@@ -160,7 +160,7 @@ def install_stubs():
     class MjModel:
         @staticmethod
         def from_xml_path(path):
-            assert path.endswith("env01.xml"), path
+            assert path.endswith(("env01.xml", "env06.xml")), path     # env06.xml == env01.xml (byte-identical scene)
             return FakeModel(O.model())
     mj.MjModel = MjModel
     mj.mj_id2name = lambda model, typ, i: names[i]
@@ -272,6 +272,7 @@ def main():
     from so100_mujoco_rl.envs.env01_v1 import Env01
     from so100_mujoco_rl.envs.env02_v1 import Env02
     from so100_mujoco_rl.envs.env05_v1 import Env05
+    from so100_mujoco_rl.envs.env06_v1 import Env06
     from so100_mujoco_rl.envs import env03_v1
 
     rs = np.random.RandomState(20240801)
@@ -410,6 +411,32 @@ def main():
         st = {"action": f(a), "inject": f(inj), "obs": f(ob), "reward": float(rew_), "terminated": bool(term),
               "qpos": f(env.data.qpos), "qvel": f(env.data.qvel), "time": env.data.time, "reset_after": False}
         if term:
+            RNG.phase = 1
+            ob2, _ = env.reset(); st["reset_after"] = True; st["reset_obs"] = f(ob2)
+        rec["steps"].append(st)
+    trajs.append(rec)
+    # Env06 (appended last so the indices above stay put): random run with resets (block memory persists across
+    # episodes), then a reach run: the cube is teleported onto the stale end effector and STAYS there (Env06 does not
+    # re-randomise), small arm actions + a closing jaw, so the gripper term varies step to step.
+    trajs.append(run(Env06, 6, 50, 61, 1.0, episodes_reset_every=20))
+    env = Env06(); r2 = np.random.RandomState(79)
+    inj = r2.random_sample(16).astype(np.float32); RNG.begin(inj); RNG.phase = 1
+    ob, _ = env.reset()
+    rec = {"kind": 6, "flags": PHYS_FLAGS, "reset_inject": f(inj), "reset_obs": f(ob), "steps": []}
+    for t in range(40):
+        a = np.clip(r2.uniform(-1, 1, 6) * (1.0 if t < 8 else 0.02), -1, 1).astype(np.float32)
+        if t >= 8:
+            a[5] = 1.0 if t < 30 else -1.0                                # close, then open the jaw
+        inj = r2.random_sample(16).astype(np.float32); RNG.begin(inj); RNG.phase = 0
+        pre = None
+        if t in (8, 20):
+            ee = env.get_end_effector_pos()
+            env.data.qpos[6:9] = ee; env.data.xpos[8] = ee
+            pre = {"cube_qpos": f(env.data.qpos[6:9]), "cube_xpos": f(env.data.xpos[8])}
+        ob, rew_, term, trunc, info = env.step(a)
+        st = {"action": f(a), "inject": f(inj), "obs": f(ob), "reward": float(rew_), "terminated": bool(term),
+              "qpos": f(env.data.qpos), "qvel": f(env.data.qvel), "time": env.data.time, "reset_after": False, "pre_teleport": pre}
+        if t == 25:                                                       # second episode: last_block_pos != block_pos afterwards
             RNG.phase = 1
             ob2, _ = env.reset(); st["reset_after"] = True; st["reset_obs"] = f(ob2)
         rec["steps"].append(st)

@@ -62,7 +62,7 @@ def test_projection(pure):
     assert pure["projection"][0]["uv"] == [425, 845]
 
 
-@pytest.mark.parametrize("idx", range(7))
+@pytest.mark.parametrize("idx", range(9))
 def test_trajectory_replay(trajs, idx):
     """Reference Python over oracle physics == oracle C task layer over the same physics."""
     tr = trajs[idx]
@@ -100,4 +100,5 @@ def test_meta_constants(golden_dir):
     assert meta["joint_names"] == ["Rotation", "Pitch", "Elbow", "Wrist_Pitch", "Wrist_Roll", "Jaw"]
     ids = {r["id"]: r for r in meta["registry"]}
     assert ids["Env01-v1"]["max_episode_steps"] == 4000 and ids["Env05-v1"]["max_episode_steps"] == 6000
+    assert ids["Env06-v1"]["max_episode_steps"] == 6000 and ids["Env06-v1"]["reward_threshold"] == 8000
     assert meta["frame_skip"] == 16
