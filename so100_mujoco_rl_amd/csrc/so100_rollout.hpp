@@ -27,6 +27,19 @@ struct RolloutArgs {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Optional cycle accounting of the persistent kernel's phases (tools/rollout_prof.py builds a side library with
+// -DSO100_ROLLOUT_PROF; the product library compiles these to nothing).  Slots: see tools/rollout_prof.py.
+#ifdef SO100_ROLLOUT_PROF
+__device__ long long so100_prof[32];
+#define SO100_PROF_DECL long long pt_[16] = {}; long long pc_ = __builtin_readcyclecounter();
+#define SO100_PROF(slot) do { const long long n_ = __builtin_readcyclecounter(); pt_[slot] += n_ - pc_; pc_ = n_; } while (0)
+#define SO100_PROF_FLUSH(base) do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 8; i_++) so100_prof[(base) + i_] = pt_[i_]; } while (0)
+#else
+#define SO100_PROF_DECL
+#define SO100_PROF(slot) do {} while (0)
+#define SO100_PROF_FLUSH(base) do {} while (0)
+#endif
+
 // Policy hidden layers on the matrix cores: per tower and layer, H[64 envs][64 units] = tanh(X[64][K] W^T + b) is a genuine
 // contraction (K = 16 / 64).  v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain, so results are bit-compatible
 // with the VALU policy kernel).  4 waves = one per SIMD: wave w owns tower w>>1, env rows [32(w&1), +32) and both 32-unit
@@ -83,8 +96,10 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __syncthreads();
     StepResult last{}; float last_obs[OD];
     StepCtx ctx{}; float ustep[8] = {}; float cstale[3] = {};
+    SO100_PROF_DECL
 #pragma unroll 1
     for (int t = 0; t < ra.T; t++) {
+        SO100_PROF(7);
         // ---- layer 1: K = ODP
         {
             f32x16 acc0, acc1;
@@ -121,6 +136,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
             }
         }
         __syncthreads();
+        SO100_PROF(0);                                             // policy hidden layers (MFMA + tanh + 2 barriers)
         float* row = ra.buf + ((size_t)t*p.n + (size_t)env)*(OD + 10);
         if (wave == 0) {
             // ---- head (VALU, lane = env): mean -> sample -> clip; then the physics phase
@@ -156,6 +172,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
             draw8(p, p.env_id_offset + (uint32_t)env, (uint32_t)e.rngc, 0, nullptr, ustep);
             e.rngc++;
             env_step_pre<KIND>(e, act, ustep, p, ctx);
+            SO100_PROF(1);                                         // head + noise + row + env_step_pre (wave 0)
         } else if (wave == 2) {
             float v = hd[7*64 + 12];
 #pragma unroll 8
@@ -203,8 +220,10 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                     if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
 #pragma unroll
                     for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
+                    SO100_PROF(2);                                 // trig (wave 0)
                 }
                 __syncthreads();
+                SO100_PROF(3);                                     // barrier 1 wait
                 if (wave == 1) {
                     float v1[6];
 #pragma unroll
@@ -212,19 +231,24 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                     arm_bias<float>(v1, A);
 #pragma unroll
                     for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
+                    SO100_PROF(4);                                 // RNEA (wave 1)
                 } else if (wave == 0) {
                     arm_mass<float>(A);
                     arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
+                    SO100_PROF(4);                                 // CRBA + factor (wave 0)
                 } else if (wave == 2 && cube_live) {
                     if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
                     cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
+                    SO100_PROF(4);                                 // cube_prepare (wave 2)
                 }
                 __syncthreads();
-                if (wave == 2 && cube_live) cube_finish<float>(cb, p.flags, p.contact_iters, cprep);   // ... Newton + Euler behind the arm's solve
+                SO100_PROF(5);                                     // barrier 2 wait
+                if (wave == 2 && cube_live) { cube_finish<float>(cb, p.flags, p.contact_iters, cprep); SO100_PROF(6); }   // ... Newton + Euler behind the arm's solve
                 if (wave == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
                     arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
+                    SO100_PROF(6);                                 // solve + integrate (wave 0)
                 }
             }
             if (cube_live) {
@@ -271,6 +295,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         }
         __syncthreads();
     }
+    if (wave < 3) SO100_PROF_FLUSH(8*wave);
     if (wave == 0 && live) {
         store_env_state<KIND>(state, p.n, env, e);
         if (ra.T > 0) {

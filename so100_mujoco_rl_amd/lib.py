@@ -12,7 +12,7 @@ import numpy as np
 import torch  # imported BEFORE the .so so that both bind to the same libamdhip64 (see csrc/Makefile)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libso100sim.so")
+LIB_PATH = os.environ.get("SO100_LIB", os.path.join(_HERE, "libso100sim.so"))   # SO100_LIB: A/B builds of the same ABI (tools/)
 
 ENV01, ENV02, ENV03, ENV04, ENV05, ENV06 = 1, 2, 3, 4, 5, 6
 F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
