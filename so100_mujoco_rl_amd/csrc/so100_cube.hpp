@@ -51,6 +51,10 @@ template <> struct EdgeDir<0> { static constexpr double d[3] = { 0,  1, 1 }; };
 template <> struct EdgeDir<1> { static constexpr double d[3] = { 0, -1, 1 }; };
 template <> struct EdgeDir<2> { static constexpr double d[3] = { -1, 0, 1 }; };
 template <> struct EdgeDir<3> { static constexpr double d[3] = { 1,  0, 1 }; };
+// The linear part of every edge row is a constant with two non-zero entries, d = sa e_A + e_z (A = tangential axis,
+// sa = +-1): products with it are written out as signed adds (`0.0f * x` is not folded by the compiler under IEEE rules).
+template <int E> struct EdgeAxis { static constexpr int A = E < 2 ? 1 : 0; static constexpr bool pos = EdgeDir<E>::d[E < 2 ? 1 : 0] > 0; };
+template <int E, typename T> SO100_HD T edge_dot(const T v[3]) { return (EdgeAxis<E>::pos ? v[EdgeAxis<E>::A] : -v[EdgeAxis<E>::A]) + v[2]; }   // d_E . v
 
 template <typename T> struct CubeRows {
     bool act[4];
@@ -62,23 +66,24 @@ template <typename T> struct CubeRows {
 // row (S,E): jar = b + J x,  J = [dir_E ; rl[S] x dl[E]];  accumulates cost / gradient / Hessian
 template <int S, int E, typename T>
 SO100_HD void cube_row_accum(const CubeRows<T>& r, const T x[6], T& cost, T g[6], T Hm[21], bool want_gh) {
-    T J[6];
-    J[0] = T(EdgeDir<E>::d[0]); J[1] = T(EdgeDir<E>::d[1]); J[2] = T(EdgeDir<E>::d[2]);
-    cross(r.rl[S], r.dl[E], J + 3);
-    T jar = r.b[S][E];
-#pragma unroll
-    for (int i = 0; i < 6; i++) jar += J[i]*x[i];
+    constexpr int A = EdgeAxis<E>::A; constexpr bool pos = EdgeAxis<E>::pos;
+    T ja[3]; cross(r.rl[S], r.dl[E], ja);
+    T jar = r.b[S][E] + edge_dot<E>(x);
+    jar += ja[0]*x[3]; jar += ja[1]*x[4]; jar += ja[2]*x[5];
     const bool on = r.act[S] && jar < T(0);
     const T D = on ? r.arinv[S][E] : T(0);             // 1/R of the row when active
     cost += T(0.5)*D*jar*jar;
     if (want_gh) {
-        const T dj = D*jar;
+        const T dj = D*jar, sD = pos ? D : -D;
+        g[A] += pos ? dj : -dj; g[2] += dj;
+        Hm[SO100_TRI(A, A)] += D; Hm[SO100_TRI(2, A)] += sD; Hm[SO100_TRI(2, 2)] += D;
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            g[i] += dj*J[i];
-            const T dji = D*J[i];
+        for (int i = 0; i < 3; i++) {
+            const T dji = D*ja[i];
+            g[3 + i] += jar*dji;
+            Hm[SO100_TRI(3 + i, A)] += pos ? dji : -dji; Hm[SO100_TRI(3 + i, 2)] += dji;
 #pragma unroll
-            for (int j = 0; j <= i; j++) Hm[SO100_TRI(i, j)] += dji*J[j];
+            for (int j = 0; j <= i; j++) Hm[SO100_TRI(3 + i, 3 + j)] += dji*ja[j];
         }
     }
 }
@@ -98,15 +103,33 @@ SO100_HD T cube_rows_eval(const CubeRows<T>& r, const T x[6], T g[6], T Hm[21], 
 #undef SO100_ACC
     return cost;
 }
+// gradient only (no cost, no Hessian): the cheap optimality test of the warm start
+template <int S, int E, typename T>
+SO100_HD void cube_row_grad(const CubeRows<T>& r, const T x[6], T g[6]) {
+    constexpr int A = EdgeAxis<E>::A; constexpr bool pos = EdgeAxis<E>::pos;
+    T ja[3]; cross(r.rl[S], r.dl[E], ja);
+    T jar = r.b[S][E] + edge_dot<E>(x);
+    jar += ja[0]*x[3]; jar += ja[1]*x[4]; jar += ja[2]*x[5];
+    const T dj = (r.act[S] && jar < T(0)) ? r.arinv[S][E]*jar : T(0);
+    g[A] += pos ? dj : -dj; g[2] += dj;
+    g[3] += dj*ja[0]; g[4] += dj*ja[1]; g[5] += dj*ja[2];
+}
+template <typename T>
+SO100_HD void cube_rows_grad(const CubeRows<T>& r, const T x[6], T g[6]) {
+    const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { g[i] = m*x[i]; g[3+i] = I*x[3+i]; }
+#define SO100_ACC(S) cube_row_grad<S, 0>(r, x, g); cube_row_grad<S, 1>(r, x, g); cube_row_grad<S, 2>(r, x, g); cube_row_grad<S, 3>(r, x, g);
+    SO100_ACC(0) SO100_ACC(1) SO100_ACC(2) SO100_ACC(3)
+#undef SO100_ACC
+}
 // line-search helpers: per row jar(alpha) = j0 + alpha jd
 template <int S, int E, typename T>
 SO100_HD void cube_row_lin(const CubeRows<T>& r, const T x[6], const T dx[6], T j0[4][4], T jd[4][4]) {
-    T J[6];
-    J[0] = T(EdgeDir<E>::d[0]); J[1] = T(EdgeDir<E>::d[1]); J[2] = T(EdgeDir<E>::d[2]);
-    cross(r.rl[S], r.dl[E], J + 3);
-    T a = r.b[S][E], b = T(0);
+    T ja[3]; cross(r.rl[S], r.dl[E], ja);
+    T a = r.b[S][E] + edge_dot<E>(x), b = edge_dot<E>(dx);
 #pragma unroll
-    for (int i = 0; i < 6; i++) { a += J[i]*x[i]; b += J[i]*dx[i]; }
+    for (int i = 0; i < 3; i++) { a += ja[i]*x[3 + i]; b += ja[i]*dx[3 + i]; }
     j0[S][E] = a; jd[S][E] = b;
 }
 template <typename T>
@@ -122,13 +145,12 @@ SO100_HD void cube_phi(const CubeRows<T>& r, const T j0[4][4], const T jd[4][4],
         }
 }
 template <int S, int E, typename T>
-SO100_HD void cube_row_setup(CubeRows<T>& r, const T a0[3], const T vl[3], const T va[3], T Kimpdist) {
+SO100_HD void cube_row_setup(CubeRows<T>& r, const T a0[3], const T vl[3], const T va[3], T Kimpdist, T rinv) {
     T ja[3]; cross(r.rl[S], r.dl[E], ja);
-    const T d0 = T(EdgeDir<E>::d[0]), d1 = T(EdgeDir<E>::d[1]), d2 = T(EdgeDir<E>::d[2]);
-    const T jv = d0*vl[0] + d1*vl[1] + d2*vl[2] + dot(ja, va);
-    const T ja0 = d0*a0[0] + d1*a0[1] + d2*a0[2];                 // angular a0 is zero (isotropic, no torque)
+    const T jv = edge_dot<E>(vl) + dot(ja, va);
+    const T ja0 = edge_dot<E>(a0);                                 // angular a0 is zero (isotropic, no torque)
     r.b[S][E] = ja0 + T(so100g::SOLREF_B)*jv + Kimpdist;
-    r.arinv[S][E] = trcp(r.R[S]);
+    r.arinv[S][E] = rinv;
 }
 
 // One cube substep in two halves (the persistent rollout kernel places a workgroup barrier between them so that the
@@ -150,33 +172,31 @@ SO100_HD void cube_prepare(const Cube<T>& c, const T applied[3], unsigned flags,
         // ---- mjc_PlaneBox: corners below the centre and at / below the plane; first four in corner order
         const T hs = T(so100g::CUBE_HALF);
         const T cdist = c.pos[2];
-        bool hit[8]; T dist8[8]; int slot[8]; int cnt = 0;
+        unsigned mask = 0u;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const T sx = (k & 1) ? hs : -hs, sy = (k & 2) ? hs : -hs, sz = (k & 4) ? hs : -hs;
             const T ld = Rm[6]*sx + Rm[7]*sy + Rm[8]*sz;
-            const bool hk = !(cdist + ld > T(0) || ld > T(0)) && cnt < 4;
-            hit[k] = hk; dist8[k] = cdist + ld; slot[k] = cnt; cnt += hk ? 1 : 0;
+            mask |= !(cdist + ld > T(0) || ld > T(0)) ? (1u << k) : 0u;
         }
-        T dist[4];
+        T dist[4], rinv[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            r.act[s] = false; dist[s] = T(0);
-            T v[3] = { T(0), T(0), T(0) };
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const bool sel = hit[k] && slot[k] == s;
-                if (sel) {
-                    r.act[s] = true; dist[s] = dist8[k];
-                    v[0] = (k & 1) ? hs : -hs; v[1] = (k & 2) ? hs : -hs; v[2] = (k & 4) ? hs : -hs;
-                }
-            }
+        for (int s = 0; s < 4; s++) {                             // slot s = the s-th hit in corner order
+            const bool act = mask != 0u;
+            const int k = act ? __builtin_ctz(mask) : 0;
+            mask &= mask - 1u;
+            r.act[s] = act;
+            const T sx = (k & 1) ? hs : -hs, sy = (k & 2) ? hs : -hs, sz = (k & 4) ? hs : -hs;
+            const T ld = Rm[6]*sx + Rm[7]*sy + Rm[8]*sz;
+            dist[s] = act ? cdist + ld : T(0);
+            const T v[3] = { act ? sx : T(0), act ? sy : T(0), act ? sz : T(0) };
             // contact point = corner - n dist/2; relative to the centre, in the body frame: v - R^T n dist/2
             const T hd = T(0.5)*dist[s];
             r.rl[s][0] = v[0] - Rm[6]*hd; r.rl[s][1] = v[1] - Rm[7]*hd; r.rl[s][2] = v[2] - Rm[8]*hd;
             const T imp = impedance(tabs(dist[s]));
             // R = 2 mu^2 * (1-imp)/imp * diagApprox, diagApprox = (1 + mu^2)/m, mu = 1
             r.R[s] = T(4.0/so100g::CUBE_MASS)*(T(1) - imp)*trcp(imp);
+            rinv[s] = trcp(r.R[s]);
             dist[s] = T(so100g::SOLREF_K)*imp*dist[s];            // K imp dist
         }
         // edge directions in the body frame: dl = R^T dir
@@ -185,8 +205,8 @@ SO100_HD void cube_prepare(const Cube<T>& c, const T applied[3], unsigned flags,
         SO100_DL(0) SO100_DL(1) SO100_DL(2) SO100_DL(3)
 #undef SO100_DL
         const T vl[3] = { c.vel[0], c.vel[1], c.vel[2] }, va[3] = { c.vel[3], c.vel[4], c.vel[5] };
-#define SO100_SETUP(S) cube_row_setup<S, 0>(r, a0, vl, va, dist[S]); cube_row_setup<S, 1>(r, a0, vl, va, dist[S]); \
-                       cube_row_setup<S, 2>(r, a0, vl, va, dist[S]); cube_row_setup<S, 3>(r, a0, vl, va, dist[S]);
+#define SO100_SETUP(S) cube_row_setup<S, 0>(r, a0, vl, va, dist[S], rinv[S]); cube_row_setup<S, 1>(r, a0, vl, va, dist[S], rinv[S]); \
+                       cube_row_setup<S, 2>(r, a0, vl, va, dist[S], rinv[S]); cube_row_setup<S, 3>(r, a0, vl, va, dist[S], rinv[S]);
         SO100_SETUP(0) SO100_SETUP(1) SO100_SETUP(2) SO100_SETUP(3)
 #undef SO100_SETUP
     }
@@ -207,6 +227,17 @@ SO100_HD void cube_finish(Cube<T>& c, unsigned flags, int iters, const CubePrep<
             const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
             for (int it = 0; it < iters; it++) {
                 T g[6], Hm[21], Dinv[6], dx[6];
+                // Cheap optimality test of the current x (at rest: the warm start) from the gradient alone.  H >= M, so the
+                // Newton step dx = -H^-1 g obeys dx'M dx <= g'M^-1 g =: E; with I = (2/3) m half^2 both step measures of the
+                // convergence test below are then < sqrt(1.5 E / m).  A resting cube -- the common case: one gradient
+                // evaluation instead of gradient + Hessian + LDL^T -- keeps its x; threshold = a quarter of that tolerance.
+                {
+                    cube_rows_grad(r, x, g);
+                    const T E = (g[0]*g[0] + g[1]*g[1] + g[2]*g[2])*T(1.0/so100g::CUBE_MASS)
+                              + (g[3]*g[3] + g[4]*g[4] + g[5]*g[5])*T(1.0/so100g::CUBE_INERTIA);
+                    const T tq = sizeof(T) == 4 ? T(0.25e-4) : T(0.25e-11);
+                    if (E < tq*tq*T(so100g::CUBE_MASS/1.5)) break;
+                }
 #if !defined(__HIPCC__)
                 g_dbg_newton_iters++;
 #endif
