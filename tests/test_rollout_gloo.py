@@ -65,6 +65,7 @@ def _worker(rank, world, port, n_local, T, q):
         else:
             assert full is None
             q.put(("ok", None, None))
+        dist.barrier()                                       # nobody tears its sockets down while a peer is still receiving
     except Exception as e:                                   # pragma: no cover
         import traceback
         q.put(("err", traceback.format_exc(), None))
