@@ -58,6 +58,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
     __shared__ float h1t[2][64][LD];
     __shared__ float h2t[2][64][LD];
+    __shared__ float xmean[6][64];                                // action means, two per wave (waves 0, 1, 3 -> wave 0)
+    __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
     __shared__ float xq[18][64];                                  // physics split: sin q, cos q, v of env = lane (wave 0 -> wave 1)
     __shared__ float xc[24][64];                                  //                cube state hand-over (wave 0 <-> wave 2)
     __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
@@ -92,6 +94,12 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         if (live) load_env_state<KIND>(state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
 #pragma unroll
         for (int k = 0; k < ODP; k++) oxt[lane][k] = (live && k < OD) ? ra.obs_in[(size_t)env*OD + k] : 0.0f;
+    }
+    if (wave == 3 && ra.T > 0) {
+        float eps[8];
+        policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0, p.seed_lo, p.seed_hi, eps);
+#pragma unroll
+        for (int a = 0; a < 6; a++) xn[a][lane] = eps[a];
     }
     __syncthreads();
     StepResult last{}; float last_obs[OD];
@@ -138,23 +146,32 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         __syncthreads();
         SO100_PROF(0);                                             // policy hidden layers (MFMA + tanh + 2 barriers)
         float* row = ra.buf + ((size_t)t*p.n + (size_t)env)*(OD + 10);
-        if (wave == 0) {
-            // ---- head (VALU, lane = env): mean -> sample -> clip; then the physics phase
-            float mean[6];
-#pragma unroll
-            for (int a = 0; a < 6; a++) mean[a] = hd[7*64 + a];
+        // ---- heads (VALU, lane = env): the 6 x 64 mean head is split two actions per wave over waves 0, 1, 3 and the
+        //      value head runs on wave 2; each mean is the same k-ordered fmaf chain as in the stand-alone policy kernel
+        if (wave != 2) {
+            const int a0 = wave == 0 ? 0 : (wave == 1 ? 2 : 4);
+            float m0 = hd[7*64 + a0], m1 = hd[7*64 + a0 + 1];
 #pragma unroll 4
             for (int k = 0; k < 64; k += 4) {
                 const float x0 = h2t[0][lane][k], x1 = h2t[0][lane][k+1], x2 = h2t[0][lane][k+2], x3 = h2t[0][lane][k+3];
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(&hd[a*64 + k]);
-                    mean[a] = __builtin_fmaf(m4.x, x0, mean[a]); mean[a] = __builtin_fmaf(m4.y, x1, mean[a]);
-                    mean[a] = __builtin_fmaf(m4.z, x2, mean[a]); mean[a] = __builtin_fmaf(m4.w, x3, mean[a]);
-                }
+                const float4 w0 = *reinterpret_cast<const float4*>(&hd[a0*64 + k]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&hd[(a0 + 1)*64 + k]);
+                m0 = __builtin_fmaf(w0.x, x0, m0); m0 = __builtin_fmaf(w0.y, x1, m0); m0 = __builtin_fmaf(w0.z, x2, m0); m0 = __builtin_fmaf(w0.w, x3, m0);
+                m1 = __builtin_fmaf(w1.x, x0, m1); m1 = __builtin_fmaf(w1.y, x1, m1); m1 = __builtin_fmaf(w1.z, x2, m1); m1 = __builtin_fmaf(w1.w, x3, m1);
             }
-            float eps[8];
-            policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)t, p.seed_lo, p.seed_hi, eps);
+            xmean[a0][lane] = m0; xmean[a0 + 1][lane] = m1;
+        } else {
+            float v = hd[7*64 + 12];
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) v = __builtin_fmaf(hd[6*64 + k], h2t[1][lane][k], v);
+            if (live) row[OD + 8] = v;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            // ---- sample -> clip -> rollout row; then the physics phase.  The noise was drawn by wave 3 a step ago.
+            float mean[6], eps[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) { mean[a] = xmean[a][lane]; eps[a] = xn[a][lane]; }
             float act[6], lp = 0.0f;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
@@ -173,11 +190,6 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
             e.rngc++;
             env_step_pre<KIND>(e, act, ustep, p, ctx);
             SO100_PROF(1);                                         // head + noise + row + env_step_pre (wave 0)
-        } else if (wave == 2) {
-            float v = hd[7*64 + 12];
-#pragma unroll 8
-            for (int k = 0; k < 64; k++) v = __builtin_fmaf(hd[6*64 + k], h2t[1][lane][k], v);
-            if (live) row[OD + 8] = v;
         }
         // ---- physics phase, split over the waves: per substep wave 1 computes the RNEA bias force while wave 0
         //      computes the CRBA mass matrix and factorises it; wave 0 then solves, integrates and publishes q, v.
@@ -224,6 +236,12 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 }
                 __syncthreads();
                 SO100_PROF(3);                                     // barrier 1 wait
+                if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
+                    float eps[8];
+                    policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
+#pragma unroll
+                    for (int a = 0; a < 6; a++) xn[a][lane] = eps[a];
+                }
                 if (wave == 1) {
                     float v1[6];
 #pragma unroll
