@@ -152,7 +152,8 @@ def main():
     # two chunk buffers: while chunk i is gathered to the learner over RCCL (async, on the collective's own stream),
     # the next rollout chunk is already being produced into buffer 1-i
     chunks = [torch.zeros(T, n, k, device=dev) for _ in range(2 if use_dist else 1)]
-    gathered = [torch.zeros(T, n, k, device=dev) for _ in range(world)] if (use_dist and rank == 0) else None
+    # (the learner rank double-buffers the receive side too: a consumer of chunk i never races the gather of chunk i+1)
+    gathered = [[torch.zeros(T, n, k, device=dev) for _ in range(world)] for _ in range(2)] if (use_dist and rank == 0) else None
     pending = [None, None]
     noise = torch.empty(n, 6, device=dev)
 
@@ -193,7 +194,7 @@ def main():
             if use_dist:
                 # RCCL: rollout chunk -> learner rank.  The collective is ordered after the producing kernel on this
                 # stream and runs on its own stream; nothing waits for it until this buffer is reused (two chunks later).
-                pending[ci] = dist.gather(chunk, [gb[:Tc] for gb in gathered] if gathered is not None else None, dst=0, async_op=True)
+                pending[ci] = dist.gather(chunk, [gb[:Tc] for gb in gathered[ci]] if gathered is not None else None, dst=0, async_op=True)
 
     def sync():
         for i, wk in enumerate(pending):

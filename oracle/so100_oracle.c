@@ -882,6 +882,21 @@ void so100o_env_step(const so100o_model* m, so100o_env* e, const float* a, const
         for (int i = 0; i < 6; i++) e->cmd[i] = (double)newcmd[i];
     }
 
+    /* Non-finite state guard (NOT reference behaviour; mirrors so100_task.hpp::env_step_finish): MuJoCo answers a
+     * NaN / > 1e10 state with a warning + mj_resetData and the reference adds nothing, so a NaN action would poison
+     * the rest of the episode.  The product ends that env's episode instead (terminated, reward 0, terminal obs 0). */
+    {
+        int bad = !isfinite(reward);
+        for (int i = 0; i < 13; i++) bad |= !isfinite(d->qpos[i]) || (i < 9 && fabs(d->qpos[i]) >= 1e10);
+        for (int i = 0; i < 12; i++) bad |= !isfinite(d->qvel[i]) || fabs(d->qvel[i]) >= 1e10;
+        for (int i = 0; i < od; i++) bad |= !isfinite(obs[i]);
+        if (bad) {
+            term = 1; reward = 0.0; e->bad_state = 1;
+            for (int i = 0; i < od; i++) obs[i] = 0.0f;
+            if (!reach_kind(e->kind)) { for (int i = 0; i < 6; i++) e->last_angvel[i] = 0.0; e->have_last_angvel = 0; }
+        }
+    }
+
     /* TimeLimit (gymnasium) + DummyVecEnv auto-reset (stable_baselines3) */
     e->elapsed_steps++;
     int trunc = (e->max_episode_steps > 0 && e->elapsed_steps >= e->max_episode_steps);

@@ -71,6 +71,7 @@ class Env(C.Structure):
         ("space_min", d_ * 3), ("space_max", d_ * 3), ("block_speed", d_),
         ("block_target", d_ * 3), ("target_dt", d_), ("target_time", d_),
         ("have_last_angvel", C.c_int), ("last_angvel", d_ * 6),
+        ("bad_state", C.c_int),
         ("block_position_updated", C.c_int),
     ]
 

@@ -24,7 +24,7 @@ struct SimParams {
 // ---- per-env persistent state ---------------------------------------------------------------------
 // bits of EnvState::bits
 enum : int { B_HAS_PREV = 1, B_HAVE_BLOCK = 2, B_HAVE_LAST_BLOCK = 4, B_HAVE_CENTER = 8, B_HAVE_ANGVEL = 16,
-             B_BLOCK_UPDATED = 32, B_ANTIGRAV = 64 };
+             B_BLOCK_UPDATED = 32, B_ANTIGRAV = 64, B_BAD_STATE = 128 /* latched: a non-finite state ended an episode */ };
 
 struct EnvState {
     float q[6];                 // arm joint angles                      (qpos[0:6])
@@ -427,6 +427,32 @@ template <int KIND> SO100_HD StepResult env_step_finish(EnvState& e, float rewar
                                                          const float* inject, const float* start_tab, float* obs, float* terminal_obs) {
     float u[8];
     StepResult r;
+    // Non-finite state guard.  MuJoCo answers a NaN / > 1e10 qpos, qvel or qacc with a warning and mj_resetData
+    // (mj_checkPos / mj_checkVel / mj_checkAcc); the reference adds nothing, so one NaN action poisons data.ctrl (Env01/02)
+    // or the command integrator (Env03-05) for the rest of the episode.  Here that env's episode ends instead:
+    // terminated, reward 0, terminal observation 0, B_BAD_STATE latched in `bits`, then the normal auto-reset; the other
+    // envs of the batch never see it.
+    {
+        float z = reward*0.0f, mx = 0.0f;                          // x*0 is NaN for NaN / inf (and is not folded under IEEE rules)
+#pragma unroll
+        for (int i = 0; i < 6; i++) { z += e.q[i]*0.0f + e.v[i]*0.0f + e.cube.vel[i]*0.0f; mx = tmax(mx, tmax(tabs(e.q[i]), tabs(e.v[i]))); mx = tmax(mx, tabs(e.cube.vel[i])); }
+#pragma unroll
+        for (int i = 0; i < 3; i++) { z += e.cube.pos[i]*0.0f; mx = tmax(mx, tabs(e.cube.pos[i])); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) z += e.cube.quat[i]*0.0f;
+#pragma unroll
+        for (int i = 0; i < obs_dim<KIND>(); i++) z += obs[i]*0.0f;
+        if (!(z == 0.0f) || !(mx < 1.0e10f)) {
+            term = true; reward = 0.0f; e.bits |= B_BAD_STATE;
+#pragma unroll
+            for (int i = 0; i < obs_dim<KIND>(); i++) obs[i] = 0.0f;
+            if (uses_group<KIND>(3)) {                             // the one pose memory that survives env_reset (ref: env_base_01.py:170-177)
+#pragma unroll
+                for (int i = 0; i < 6; i++) e.av[i] = 0.0f;
+                e.bits &= ~B_HAVE_ANGVEL;
+            }
+        }
+    }
     r.reward = reward;
     e.elapsed++;
     const bool trunc = p.max_episode_steps > 0 && e.elapsed >= p.max_episode_steps;

@@ -39,9 +39,9 @@ def _worker(rank, world, port, n_local, T, q):
                         torch.from_numpy((term | trunc).astype(np.float32)), torch.full((n_local,), float(rank)), torch.zeros(n_local))
             obs = o2.copy()
         full = gather_rollout(chunk.buf, dst=0)
-        # bench.py's pattern: two chunk buffers, async gather of buffer i while buffer 1-i is being produced
+        # bench.py's pattern: two chunk buffers (send AND receive side), async gather of buffer i while buffer 1-i is produced
         bufs = [torch.zeros(T, n_local, 25), torch.zeros(T, n_local, 25)]
-        recv = [torch.zeros(T, n_local, 25) for _ in range(world)] if rank == 0 else None
+        recv = [[torch.zeros(T, n_local, 25) for _ in range(world)] for _ in range(2)] if rank == 0 else None
         pending = [None, None]; seen = []
         ci = 0
         for c in range(5):
@@ -49,15 +49,17 @@ def _worker(rank, world, port, n_local, T, q):
             ci ^= 1
             if pending[ci] is not None:
                 pending[ci].wait(); pending[ci] = None
-                if rank == 0: seen.append([float(r[0, 0, 0]) for r in recv])
+                if rank == 0: seen.append([float(r[0, 0, 0]) for r in recv[ci]])
             bufs[ci][:Tc] = 100.0 * c + rank
-            pending[ci] = dist.gather(bufs[ci][:Tc], [r[:Tc] for r in recv] if rank == 0 else None, dst=0, async_op=True)
+            pending[ci] = dist.gather(bufs[ci][:Tc], [r[:Tc] for r in recv[ci]] if rank == 0 else None, dst=0, async_op=True)
         for i, wk in enumerate(pending):
             if wk is not None:
                 wk.wait()
         if rank == 0:
-            assert [float(r[0, 0, 0]) for r in recv] == [400.0 + k for k in range(world)]       # last (partial) chunk, rank order
-            assert float(recv[1][2, 0, 0]) == 301.0                                            # rows beyond Tc keep chunk 3
+            assert seen == [[100.0 * c + k for k in range(world)] for c in range(3)], seen       # chunk c was complete when its buffer was reused
+            assert [float(r[0, 0, 0]) for r in recv[1]] == [400.0 + k for k in range(world)]    # last (partial) chunk, rank order
+            assert float(recv[1][1][2, 0, 0]) == 201.0                                         # rows beyond Tc keep that buffer's previous chunk
+            assert [float(r[0, 0, 0]) for r in recv[0]] == [300.0 + k for k in range(world)]
         w = torch.full((4,), float(rank + 1)); broadcast_policy([w], src=0)
         assert torch.all(w == 1.0)
         if rank == 0:
@@ -84,7 +86,8 @@ def test_sharded_rollout_gather_world2():
     [p.start() for p in procs]
     res = [q.get(timeout=120) for _ in range(world)]
     [p.join(timeout=60) for p in procs]
-    assert all(r[0] == "ok" for r in res), [r[1] for r in res if r[0] != "ok"]
+    if not all(r[0] == "ok" for r in res):
+        pytest.fail("worker failed:\n" + "\n".join(str(r[1]) for r in res if r[0] != "ok"))
     full, acts_all = [(r[1], r[2]) for r in res if r[1] is not None][0]
     total = world * n_local
     assert full.shape == (T, total, 25)
