@@ -70,6 +70,10 @@ typedef struct {
 /* One vectorised env step.  Replaces, for N envs at once, the reference chain
  *   SB3 DummyVecEnv.step_wait -> gymnasium TimeLimit.step -> EnvNN.step (ref: envs/env01_v1.py:15-37 and
  *   clones) -> mujoco.mj_step(model, data, nstep=16) -> _get_obs, including DummyVecEnv's auto-reset. */
+/* Non-finite guard (product behaviour; the reference has none and MuJoCo would mj_resetData with a warning): if an env's
+ * state, observation or reward is NaN / inf / beyond 1e10 after a step (e.g. a NaN action), that env's episode ends --
+ * done = 1, trunc = 0, reward 0, terminal observation 0 -- it is auto-reset like any other finished episode and bit 128
+ * of its "bits" state row is latched.  Other envs of the batch are unaffected. */
 typedef struct {
     const float* act_dev;          /* [N][6]  f32 in [-1,1] (ref: envs/env_base_01.py:77-83)          */
     float*       obs_dev;          /* [N][obs_dim] f32; post-auto-reset observation where done        */

@@ -778,6 +778,11 @@ void so100o_env_step(const so100o_model* m, so100o_env* e, const float* a, const
     e->rng_counter++;
     double reward = 0.0; int term = 0;
     const int od = so100o_obs_dim(e->kind);
+    /* product behaviour (so100_task.hpp::env_step_pre): a non-finite action runs as zero and ends the episode below */
+    float a_ok[6]; int bad_action = 0;
+    for (int i = 0; i < 6; i++) bad_action |= !isfinite(a[i]);
+    for (int i = 0; i < 6; i++) a_ok[i] = bad_action ? 0.0f : a[i];
+    a = a_ok;
 
     if (reach_kind(e->kind)) {
         /* env01_v1.py:15-37 / env02_v1.py:18-50 / env06_v1.py:18-50 */
@@ -886,10 +891,9 @@ void so100o_env_step(const so100o_model* m, so100o_env* e, const float* a, const
      * NaN / > 1e10 state with a warning + mj_resetData and the reference adds nothing, so a NaN action would poison
      * the rest of the episode.  The product ends that env's episode instead (terminated, reward 0, terminal obs 0). */
     {
-        int bad = !isfinite(reward);
+        int bad = bad_action || !isfinite(reward);
         for (int i = 0; i < 13; i++) bad |= !isfinite(d->qpos[i]) || (i < 9 && fabs(d->qpos[i]) >= 1e10);
         for (int i = 0; i < 12; i++) bad |= !isfinite(d->qvel[i]) || fabs(d->qvel[i]) >= 1e10;
-        for (int i = 0; i < od; i++) bad |= !isfinite(obs[i]);
         if (bad) {
             term = 1; reward = 0.0; e->bad_state = 1;
             for (int i = 0; i < od; i++) obs[i] = 0.0f;

@@ -24,7 +24,8 @@ struct SimParams {
 // ---- per-env persistent state ---------------------------------------------------------------------
 // bits of EnvState::bits
 enum : int { B_HAS_PREV = 1, B_HAVE_BLOCK = 2, B_HAVE_LAST_BLOCK = 4, B_HAVE_CENTER = 8, B_HAVE_ANGVEL = 16,
-             B_BLOCK_UPDATED = 32, B_ANTIGRAV = 64, B_BAD_STATE = 128 /* latched: a non-finite state ended an episode */ };
+             B_BLOCK_UPDATED = 32, B_ANTIGRAV = 64, B_BAD_STATE = 128 /* latched: a non-finite state ended an episode */,
+             B_BAD_ACTION = 256 /* this step's action was non-finite (consumed by env_step_finish) */ };
 
 struct EnvState {
     float q[6];                 // arm joint angles                      (qpos[0:6])
@@ -265,7 +266,15 @@ struct StepCtx {
     float old[6], ncmd[6], frac, smin[3], smax[3];       // Env03-05
 };
 
-template <int KIND> SO100_HD void env_step_pre(EnvState& e, const float a[6], const float u[8], const SimParams& p, StepCtx& c) {
+template <int KIND> SO100_HD void env_step_pre(EnvState& e, const float a_in[6], const float u[8], const SimParams& p, StepCtx& c) {
+    // a non-finite action is an error of the caller: the step runs with a zero action and env_step_finish ends the episode
+    float a[6], az = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) az += a_in[i]*0.0f;
+    const bool abad = !(az == 0.0f);
+    if (abad) e.bits |= B_BAD_ACTION;
+#pragma unroll
+    for (int i = 0; i < 6; i++) a[i] = abad ? 0.0f : a_in[i];
     if (reach_kind<KIND>()) {
         // ref: env01_v1.py:15-37 / env02_v1.py:18-50 / env06_v1.py:18-50
         c.reward = reward_base(e.q, e.cx, e.ee, e.wrist_z, (e.bits & B_HAS_PREV) != 0);
@@ -427,7 +436,7 @@ template <int KIND> SO100_HD StepResult env_step_finish(EnvState& e, float rewar
                                                          const float* inject, const float* start_tab, float* obs, float* terminal_obs) {
     float u[8];
     StepResult r;
-    // Non-finite state guard.  MuJoCo answers a NaN / > 1e10 qpos, qvel or qacc with a warning and mj_resetData
+    // Non-finite state guard (the observation is a finite function of a finite state).  MuJoCo answers a NaN / > 1e10 qpos, qvel or qacc with a warning and mj_resetData
     // (mj_checkPos / mj_checkVel / mj_checkAcc); the reference adds nothing, so one NaN action poisons data.ctrl (Env01/02)
     // or the command integrator (Env03-05) for the rest of the episode.  Here that env's episode ends instead:
     // terminated, reward 0, terminal observation 0, B_BAD_STATE latched in `bits`, then the normal auto-reset; the other
@@ -440,10 +449,8 @@ template <int KIND> SO100_HD StepResult env_step_finish(EnvState& e, float rewar
         for (int i = 0; i < 3; i++) { z += e.cube.pos[i]*0.0f; mx = tmax(mx, tabs(e.cube.pos[i])); }
 #pragma unroll
         for (int i = 0; i < 4; i++) z += e.cube.quat[i]*0.0f;
-#pragma unroll
-        for (int i = 0; i < obs_dim<KIND>(); i++) z += obs[i]*0.0f;
-        if (!(z == 0.0f) || !(mx < 1.0e10f)) {
-            term = true; reward = 0.0f; e.bits |= B_BAD_STATE;
+        if (!(z == 0.0f) || !(mx < 1.0e10f) || (e.bits & B_BAD_ACTION)) {
+            term = true; reward = 0.0f; e.bits = (e.bits | B_BAD_STATE) & ~B_BAD_ACTION;
 #pragma unroll
             for (int i = 0; i < obs_dim<KIND>(); i++) obs[i] = 0.0f;
             if (uses_group<KIND>(3)) {                             // the one pose memory that survives env_reset (ref: env_base_01.py:170-177)

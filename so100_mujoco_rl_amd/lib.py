@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("SO100_LIB", os.path.join(_HERE, "libso100sim.so"))   
 ENV01, ENV02, ENV03, ENV04, ENV05, ENV06 = 1, 2, 3, 4, 5, 6
 F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR
+B_BAD_STATE = 128            # bit of the `bits` state row latched when a non-finite state ended an episode (csrc/so100_task.hpp)
 NINJECT = 16
 
 
@@ -252,6 +253,10 @@ class So100Sim:
             if self.L.so100_state_field_index(n.encode()) >= 0:
                 self.set_field(n, torch.from_numpy(row).to(self.device))
         self.obs.copy_(torch.from_numpy(obs))
+
+    def bad_state_mask(self):
+        """bool [N]: envs whose episode was ever ended by the non-finite state guard (NaN / inf action or state)."""
+        return (self.get_field("bits", dtype=torch.int32) & B_BAD_STATE) != 0
 
     def get_field(self, name, dtype=torch.float32):
         out = torch.empty(self.n, dtype=dtype, device=self.device)

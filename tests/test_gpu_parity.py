@@ -246,6 +246,56 @@ def test_golden_trajectories_on_gpu(golden_dir, idx):
         np.testing.assert_allclose(qpos[:, 0].cpu().numpy(), tr["steps"][-1]["qpos"], rtol=0, atol=3e-5)
 
 
+@pytest.mark.parametrize("kind", [1, 5])
+def test_non_finite_action_ends_only_that_episode(kind):
+    """NaN / inf actions: that env's episode ends (done, reward 0, zero terminal obs, latched flag) and it is reset; every other
+    env -- and the poisoned envs after their reset -- keep matching the oracle, which carries the same guard."""
+    n, bad = 96, {5: float("nan"), 9: float("inf"), 70: float("-inf")}
+    hit = False
+    for t, sim, orc, og, oo, rew, done, trunc, res in _run_pair_with(kind, REF, n, 12, seed=3, poison=(4, bad)):
+        assert np.isfinite(og).all() and np.isfinite(oo).all()
+        np.testing.assert_allclose(og, oo, rtol=0, atol=2e-5 if kind == 1 else 6e-3)
+        if rew is None:
+            continue
+        assert np.isfinite(rew[0]).all()
+        np.testing.assert_array_equal(done[0].astype(bool), done[1])
+        if t == 4:
+            hit = True
+            for i in bad:
+                assert done[0][i] == 1 and trunc[0][i] == 0 and rew[0][i] == 0.0
+                np.testing.assert_array_equal(sim.terminal_obs[i].cpu().numpy(), 0.0)
+            assert done[0].sum() == len(bad)
+    assert hit
+    m = sim.bad_state_mask().cpu().numpy()
+    assert sorted(np.nonzero(m)[0].tolist()) == sorted(bad) and all(orc[i].e.bad_state == 1 for i in bad)
+    qpos, qvel = sim.get_state()
+    assert torch.isfinite(qpos).all() and torch.isfinite(qvel).all()
+
+
+def _run_pair_with(kind, flags, n, steps, seed, poison):
+    """_run_pair with the actions of step poison[0] overwritten per env by poison[1] (same values on both sides)."""
+    rs = np.random.RandomState(seed)
+    sim = _sim(kind, n, flags=flags, solver_iters=4, contact_iters=6, max_episode_steps=0, seed=seed)
+    orc = [O.OracleEnv(kind, flags=flags, iters=0, seed=seed, env_id=i) for i in range(n)]
+    for e in orc:
+        e.e.max_episode_steps = 0
+    inj = rs.random_sample((n, 16)).astype(np.float32)
+    obs_g = sim.reset(inject=torch.from_numpy(inj).cuda()).cpu().numpy().copy()
+    obs_o = np.stack([e.reset(inject=inj[i]) for i, e in enumerate(orc)])
+    yield -1, sim, orc, obs_g, obs_o, None, None, None, None
+    for t in range(steps):
+        a = np.clip(rs.uniform(-1, 1, (n, 6)) * 0.5, -1, 1).astype(np.float32)
+        if t == poison[0]:
+            for i, v in poison[1].items():
+                a[i, i % 6] = v
+        inj = rs.random_sample((n, 16)).astype(np.float32)
+        og, rg, dg, tg = sim.step(torch.from_numpy(a).cuda(), inject=torch.from_numpy(inj).cuda())
+        res = [e.step(a[i], inject=inj[i], autoreset=True) for i, e in enumerate(orc)]
+        oo = np.stack([r[0] for r in res]); ro = np.array([r[1] for r in res])
+        do = np.array([r[2] or r[3] for r in res]); to = np.array([r[3] and not r[2] for r in res])
+        yield t, sim, orc, og.cpu().numpy().copy(), oo, (rg.cpu().numpy().copy(), ro), (dg.cpu().numpy().copy(), do), (tg.cpu().numpy().copy(), to), res
+
+
 def test_state_roundtrip_and_errors():
     from so100_mujoco_rl_amd import lib
     sim = _sim(1, 100, flags=FREE)

@@ -301,3 +301,22 @@ def test_energy_conservation_passive_arm():
     swing = max(abs(O.arr(d.qvel)[:6]))
     assert swing > 0.1                          # it actually moves
     assert max(abs(np.array(Es) - E0)) < 2e-3 * abs(E0) + 2e-3
+
+
+def test_non_finite_guard_ends_episode():
+    """Product behaviour mirrored in the oracle (oracle/so100_oracle.c, so100_task.hpp::env_step_finish): a NaN action ends
+    the episode with reward 0 and a zero terminal observation, and the env is usable again after its auto-reset."""
+    for kind in (1, 2, 5, 6):
+        e = O.OracleEnv(kind, flags=O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR, iters=0, seed=1)
+        e.reset()
+        a = np.zeros(6, np.float32)
+        for _ in range(3):
+            ob, r, term, trunc, tob = e.step(a, autoreset=True)
+            assert not term and np.isfinite(ob).all()
+        a[2] = np.nan
+        ob, r, term, trunc, tob = e.step(a, autoreset=True)
+        assert term and not trunc and r == 0.0 and e.e.bad_state == 1
+        assert np.isfinite(ob).all() and (tob == 0).all()
+        ob, r, term, trunc, tob = e.step(np.zeros(6, np.float32), autoreset=True)
+        assert not term and np.isfinite(ob).all() and np.isfinite(r)
+        assert np.isfinite(O.arr(e.d.qpos)).all() and np.isfinite(O.arr(e.d.qvel)).all()
