@@ -398,7 +398,7 @@ def test_north_star_1000_steps():
     physics over 1000 env steps = 16000 substeps on identical seeds.  Smooth bounded actions (a random walk), the
     reference-faithful arm (friction loss + limits) and the constraint-free configuration."""
     n, steps = 16, 1000
-    for flags in (ARM, FREE):
+    for flags in (ARM, FREE, REF):
         rs = np.random.RandomState(3)
         sim = _sim(1, n, flags=flags, solver_iters=3, max_episode_steps=0, seed=2)
         orc = [O.OracleEnv(1, flags=flags, iters=0, seed=2, env_id=i) for i in range(n)]
@@ -406,7 +406,7 @@ def test_north_star_1000_steps():
             e.e.max_episode_steps = 0
         inj = rs.random_sample((n, 16)).astype(np.float32)
         sim.reset(inject=torch.from_numpy(inj).cuda()); [e.reset(inject=inj[i]) for i, e in enumerate(orc)]
-        a = np.zeros((n, 6), np.float32); worst_q = worst_v = 0.0
+        a = np.zeros((n, 6), np.float32); worst_q = worst_v = worst_c = 0.0
         for t in range(steps):
             a = np.clip(a + rs.uniform(-0.2, 0.2, (n, 6)), -1, 1).astype(np.float32)
             sim.step(torch.from_numpy(a).cuda())
@@ -417,7 +417,11 @@ def test_north_star_1000_steps():
                 qo = np.stack([O.arr(e.d.qpos)[:6].copy() for e in orc]); vo = np.stack([O.arr(e.d.qvel)[:6].copy() for e in orc])
                 worst_q = max(worst_q, np.abs(qpos[:6].cpu().numpy().T - qo).max())
                 worst_v = max(worst_v, np.abs(qvel[:6].cpu().numpy().T - vo).max())
-        print(f"flags={flags}: 1000 steps, max |dq| = {worst_q:.2e} rad (scale pi), max |dqvel| = {worst_v:.2e} rad/s")
+                if flags == REF:                             # the cube: settles out of the floor after the reset, then rests
+                    co = np.stack([O.arr(e.d.qpos)[6:13].copy() for e in orc])
+                    worst_c = max(worst_c, np.abs(qpos[6:13].cpu().numpy().T - co).max())
+        print(f"flags={flags}: 1000 steps, max |dq| = {worst_q:.2e} rad (scale pi), max |dqvel| = {worst_v:.2e} rad/s, cube pose {worst_c:.2e}")
+        assert worst_c < 1e-5                               # metres / quaternion components
         assert worst_q < 1e-5 * np.pi                       # 1e-5 relative to the angle scale (ranges span +-pi)
         assert worst_v < 1e-5 * 40                          # velocities reach tens of rad/s under full-scale actions
 
