@@ -31,8 +31,8 @@ extern "C" {
 /* env kinds == the reference's registered ids Env01-v1 .. Env06-v1 (ref: __init__.py:5-45) */
 #define SO100_ENV01 1   /* ref: envs/env01_v1.py  reach, random start pose              obs 15 */
 #define SO100_ENV02 2   /* ref: envs/env02_v1.py  reach + re-randomise on reach         obs 15 */
-#define SO100_ENV03 3   /* ref: envs/env03_v1.py  look-at, moving cube (analytic detector) obs 8 */
-#define SO100_ENV04 4   /* ref: envs/env04_v1.py  look-at, jumping cube (analytic detector) obs 8 */
+#define SO100_ENV03 3   /* ref: envs/env03_v1.py  look-at, moving cube (bbox detector)    obs 8 */
+#define SO100_ENV04 4   /* ref: envs/env04_v1.py  look-at, jumping cube (bbox detector)   obs 8 */
 #define SO100_ENV05 5   /* ref: envs/env05_v1.py  look-at, analytic reprojection + noise  obs 8 */
 #define SO100_ENV06 6   /* ref: envs/env06_v1.py  reach + close the gripper (env_base_06.py) obs 15 */
 

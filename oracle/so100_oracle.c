@@ -714,12 +714,43 @@ static void obs_base(const so100o_env* e, float* obs) {       /* env_base_01.py:
     for (int i = 0; i < 6; i++) obs[i] = (float)d->qpos[i];
     for (int i = 0; i < 3; i++) { obs[6 + i] = (float)(b[i] - ee[i]); obs[9 + i] = (float)b[i]; obs[12 + i] = (float)ee[i]; }
 }
+/* env_base_02.py:129-176 get_projected_cube_bounding_box (+ _get_cube_corners): the 8 axis-aligned corners of the
+ * 2 cm cube around p are projected one by one, Nones dropped, fewer than 2 survivors => None (returns 0);
+ * box = (min_x, min_y, max_x, max_y).  Unused upstream; the product's analytic stand-in for render + YOLO in Env03/04. */
+int so100o_project_bbox(const double cam_xpos[3], const double cam_xmat[9], const double p[3], int box[4]) {
+    const double d = 0.02 / 2;
+    int n = 0;
+    for (int k = 0; k < 8; k++) {                             /* corner order of the reference: x outer, y, z inner */
+        const double c[3] = { (k & 4) ? p[0] + d : p[0] - d, (k & 2) ? p[1] + d : p[1] - d, (k & 1) ? p[2] + d : p[2] - d };
+        int uv[2];
+        if (!so100o_project(cam_xpos, cam_xmat, c, uv)) continue;
+        if (n == 0) { box[0] = box[2] = uv[0]; box[1] = box[3] = uv[1]; }
+        else {
+            if (uv[0] < box[0]) box[0] = uv[0];
+            if (uv[0] > box[2]) box[2] = uv[0];
+            if (uv[1] < box[1]) box[1] = uv[1];
+            if (uv[1] > box[3]) box[3] = uv[1];
+        }
+        n++;
+    }
+    return n >= 2;
+}
+
 static void obs_cam(const so100o_env* e, const float* u8, int noise, float* obs) {  /* env05_v1.py:32-75 */
     const so100o_data* d = &e->d;
     double cx = -1.0, cy = -1.0; int uv[2];
-    if (so100o_project(d->cam_xpos, d->cam_xmat, d->qpos + 6, uv)) {
-        cx = uv[0] / 1080.0; cy = uv[1] / 1920.0;
-        if (noise) { cx += -0.05 + 0.1*(double)u8[4]; cy += -0.05 + 0.1*(double)u8[5]; }
+    if (e->kind == 5) {
+        if (so100o_project(d->cam_xpos, d->cam_xmat, d->qpos + 6, uv)) {
+            cx = uv[0] / 1080.0; cy = uv[1] / 1920.0;
+            if (noise) { cx += -0.05 + 0.1*(double)u8[4]; cy += -0.05 + 0.1*(double)u8[5]; }
+        }
+    } else {
+        /* Env03 / Env04 (render + YOLO upstream, env_base_02.py:178-222): the detector is replaced by the bounding box of
+         * the projected cube corners with YOLO's centre arithmetic, center = (x1 + x2) // 2 / width (env_base_02.py:206-209) */
+        int box[4];
+        if (so100o_project_bbox(d->cam_xpos, d->cam_xmat, d->qpos + 6, box)) {
+            cx = ((box[0] + box[2]) / 2) / 1080.0; cy = ((box[1] + box[3]) / 2) / 1920.0;
+        }
     }
     for (int i = 0; i < 6; i++) obs[i] = (float)e->cmd[i];
     obs[6] = (float)cx; obs[7] = (float)cy;

@@ -167,6 +167,26 @@ SO100_HD bool project(const float cam_pos[3], const float cam_mat[9], const floa
     return true;
 }
 
+// 8-corner bounding box of the cube in the image; ref: env_base_02.py:129-176 (get_projected_cube_bounding_box, unused
+// upstream).  Returns false for None (fewer than two corners project into the frame); centre with YOLO's integer arithmetic
+// (env_base_02.py:206-209).  Env03 / Env04 use it in place of render + YOLO.
+SO100_HD bool project_bbox_center(const float cam_pos[3], const float cam_mat[9], const float p[3], int& cx, int& cy) {
+    const float d = 0.01f;
+    int n = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float c[3] = { (k & 4) ? p[0] + d : p[0] - d, (k & 2) ? p[1] + d : p[1] - d, (k & 1) ? p[2] + d : p[2] - d };
+        int u, v;
+        if (project(cam_pos, cam_mat, c, u, v)) {
+            if (n == 0) { x0 = x1 = u; y0 = y1 = v; }
+            else { x0 = u < x0 ? u : x0; x1 = u > x1 ? u : x1; y0 = v < y0 ? v : y0; y1 = v > y1 ? v : y1; }
+            n++;
+        }
+    }
+    cx = (x0 + x1)/2; cy = (y0 + y1)/2;
+    return n >= 2;
+}
+
 SO100_HD void set_random_block_position(EnvState& e, bool remember, float dlo, const float u[8]) {
     // ref: env01_v1.py:45-52 (dlo 0.18), env02_v1.py:52-68 and env06_v1.py:52-69 (dlo 0.22, remember); u[1] is the discarded draw
     const float dist = dlo + (0.42f - dlo)*u[0];
@@ -352,9 +372,10 @@ template <int KIND> SO100_HD float env_step_post(EnvState& e, const StepCtx& c, 
         for (int i = 0; i < 3; i++) { obs[6 + i] = e.cx[i] - e.ee[i]; obs[9 + i] = e.cx[i]; obs[12 + i] = e.ee[i]; }
     } else {
         const float h = (float)so100g::TIMESTEP;
-        // ref: env05_v1.py:32-75 (Env03/04: the same reprojection stands in for render + YOLO, no noise)
+        // ref: env05_v1.py:32-75 (Env05: centre reprojection + noise); Env03/04: the bounding box of the projected cube
+        // corners (env_base_02.py:129-176) with YOLO's centre arithmetic stands in for render + YOLO (env_base_02.py:178-222)
         float cxn = -1.0f, cyn = -1.0f; int pu, pv;
-        if (project(P.cam_pos, P.cam_mat, e.cube.pos, pu, pv)) {
+        if (KIND == 5 ? project(P.cam_pos, P.cam_mat, e.cube.pos, pu, pv) : project_bbox_center(P.cam_pos, P.cam_mat, e.cube.pos, pu, pv)) {
             cxn = (float)pu/1080.0f; cyn = (float)pv/1920.0f;
             if (KIND == 5) { cxn += -0.05f + 0.1f*u[4]; cyn += -0.05f + 0.1f*u[5]; }
         }

@@ -340,7 +340,15 @@ def main():
         env.data.cam_xpos[:] = cam; env.data.cam_xmat[:] = R
         out = env._get_projected_position(np.array(p, dtype=float))
         proj.append({"cam_xpos": f(cam), "cam_xmat": f(R), "p": f(p), "uv": None if out is None else [int(out[0]), int(out[1])]})
-    dump("pure.json", {"joint_penalty": pen, "reward_base": rew, "projection": proj})
+    # 8-corner bounding box of the cube (env_base_02.py:129-176, unused upstream; the product's stand-in for YOLO in Env03/04)
+    bbox = []
+    for cam, R, p in cases:
+        env.data.cam_xpos[:] = cam; env.data.cam_xmat[:] = R
+        env.data.qpos[6:9] = p
+        out = env.get_projected_cube_bounding_box()
+        bbox.append({"cam_xpos": f(cam), "cam_xmat": f(R), "p": f(p),
+                     "box": None if out is None else [int(out[0][0]), int(out[0][1]), int(out[1][0]), int(out[1][1])]})
+    dump("pure.json", {"joint_penalty": pen, "reward_base": rew, "projection": proj, "bbox": bbox})
 
     # ---- trajectories: reference task code over oracle physics --------------------------------
     def run(EnvCls, kind, n_steps, seed, action_scale, episodes_reset_every=None, tweak=None):

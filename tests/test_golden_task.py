@@ -62,6 +62,20 @@ def test_projection(pure):
     assert pure["projection"][0]["uv"] == [425, 845]
 
 
+def test_projected_bounding_box(pure):
+    """get_projected_cube_bounding_box (env_base_02.py:129-176), recorded from the reference's own function."""
+    L = O.lib()
+    n_box = n_none = 0
+    for c in pure["bbox"]:
+        box = (C.c_int * 4)()
+        ok = L.so100o_project_bbox(_dp(c["cam_xpos"]), _dp(c["cam_xmat"]), _dp(c["p"]), box)
+        if c["box"] is None:
+            assert ok == 0; n_none += 1
+        else:
+            assert ok == 1 and list(box) == c["box"], (list(box), c["box"]); n_box += 1
+    assert n_box > 50 and n_none > 20
+
+
 @pytest.mark.parametrize("idx", range(9))
 def test_trajectory_replay(trajs, idx):
     """Reference Python over oracle physics == oracle C task layer over the same physics."""
