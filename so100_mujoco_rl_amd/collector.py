@@ -68,10 +68,13 @@ class RolloutCollector:
                 self.sim.step(self.act, rollout_row=row)
                 self.counter += 1
         buf = self.chunk.buf[:T]
+        last_obs = self.sim.obs
         if gather_dst is not None:
             buf = gather_rollout(buf.contiguous(), dst=gather_dst)
+            last_obs = gather_rollout(last_obs.unsqueeze(0).contiguous(), dst=gather_dst)      # [1, N_total, obs_dim] on the learner rank
             if buf is None:
                 return None
+            last_obs = last_obs[0]
         out = self.chunk.unpack(buf)
-        out["last_obs"] = self.sim.obs
+        out["last_obs"] = last_obs
         return out

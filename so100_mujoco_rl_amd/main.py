@@ -3,6 +3,7 @@
     python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] train  -e Env01-v1 [--envs 4096] [--iters N]
     python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] test   -e Env01-v1 [--show-io] [--show-i]
     python -m so100_mujoco_rl_amd.main -a PPO [-m MODEL] record -e Env01-v1
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 -m so100_mujoco_rl_amd.main -a PPO train -e Env01-v1     # 8 x 4096 envs
 
 Same directory layout (models/ logs/ movies/), default model path models/{env}_{algo}/best_model.*, reward thresholds
 (6000 / 8000, ref: __init__.py:9,16) and checkpoint naming ({env}_{algo}_cp_*, ref: main.py:227-232).  Differences, all
@@ -19,9 +20,12 @@ import numpy as np
 import torch
 
 from . import constants as K
+import torch.distributed as dist
+
 from .collector import RolloutCollector
 from .lib import F_REFERENCE
 from .ppo import PPO, ActorCritic
+from .rollout import broadcast_policy
 from .vec_env import So100VecEnv, kind_from_id
 
 logging.basicConfig(level=logging.INFO, format="%(message)s")
@@ -71,10 +75,24 @@ def cli(ctx, algorithm, model):
 def train(ctx, environment, envs, iters, seed):
     algorithm = ctx.obj["ALGORITHM_NAME"]
     kind = kind_from_id(environment)
-    env = So100VecEnv(environment, envs, flags=F_REFERENCE, seed=seed, stagger_episodes=True)
+    # Multi-GPU (one process per GPU under torchrun): rank r steps global envs [r*envs, (r+1)*envs); once per rollout chunk the
+    # packed rollout goes to rank 0 over RCCL (the path's ONE collective), rank 0 learns, the policy is broadcast back.
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1 or os.environ.get("SO100_FORCE_DIST") == "1"      # SO100_FORCE_DIST: the same code path on a one-GPU box
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29544")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        if _have_sb3():
+            raise RuntimeError("multi-GPU training uses the built-in PPO learner; run SB3 single-GPU")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    lead = rank == 0
+    env = So100VecEnv(environment, envs, device=torch.device("cuda", local) if distributed else None, flags=F_REFERENCE, seed=seed,
+                      env_id_offset=rank * envs, stagger_episodes=True)
     save_dir = os.path.join(MODEL_DIR, f"{environment}_{algorithm}")
     os.makedirs(save_dir, exist_ok=True)
-    logger.info("Starting training process"); logger.info(f"Algorithm: {algorithm}"); logger.info(f"Environment: {environment} x {envs}")
+    if lead:
+        logger.info("Starting training process"); logger.info(f"Algorithm: {algorithm}"); logger.info(f"Environment: {environment} x {envs}" + (f" x {world} GPUs" if distributed else ""))
     if _have_sb3():                                          # unchanged SB3 learner over the batched VecEnv (ref: main.py:199-238)
         import stable_baselines3
         from stable_baselines3.common.callbacks import CheckpointCallback
@@ -93,37 +111,49 @@ def train(ctx, environment, envs, iters, seed):
         logger.info(f"Model: starting with {ctx.obj['MODEL_PATH']}")
     else:
         logger.info("Model: starting with new model")
+    if distributed:
+        broadcast_policy(list(learner.net.state_dict().values()), src=0)          # every rank starts from rank 0's weights
     col = RolloutCollector(env, learner.net.state_dict(), T=64)
     threshold = K.REWARD_THRESHOLD[kind]                     # StopTrainingOnRewardThreshold (ref: main.py:211)
     best, since_best, steps, t0, it = -float("inf"), 0, 0, time.time(), 0
     ep_sum = ep_cnt = 0.0
+    stop = torch.zeros(1, device=env.device)
     while True:
-        b = col.collect()
-        done = (b["dones"] > 0).any(0)                       # ep_return holds the return of the latest episode that ended in the chunk
-        if done.any():
-            ep_sum += env.sim.ep_return[done].sum().item(); ep_cnt += int(done.sum().item())
-        stats = learner.update(b)
+        b = col.collect(gather_dst=0 if distributed else None)
+        it += 1
+        if lead:
+            done = (b["dones"] > 0).any(0)[:envs]            # episode statistics from this rank's own envs
+            if done.any():                                   # ep_return holds the return of the latest episode that ended in the chunk
+                ep_sum += env.sim.ep_return[done].sum().item(); ep_cnt += int(done.sum().item())
+            stats = learner.update(b)
+            steps += b["rewards"].numel()
+            if it % 10 == 0:
+                mean_ep = ep_sum / ep_cnt if ep_cnt else float("nan")
+                logger.info(f"iter {it:5d}  timesteps {steps/1e6:8.1f} M  reward/step {stats['mean_reward']:+.4f}  ep_rew_mean {mean_ep:9.2f}  "
+                            f"value_loss {stats['value_loss']:.4f}  fps {steps/(time.time()-t0)/1e6:.1f} M")
+                score = stats["mean_reward"]
+                if score > best:
+                    best, since_best = score, 0
+                    torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt"))
+                else:
+                    since_best += 1
+                if ep_cnt and mean_ep >= threshold:
+                    logger.info(f"Stopping training: mean episode reward {mean_ep:.1f} reached the threshold {threshold}"); stop.fill_(1.0)
+                ep_sum = ep_cnt = 0.0
+            if it % 40 == 0:                                 # CheckpointCallback (ref: main.py:227-232)
+                torch.save(learner.net.state_dict(), os.path.join(save_dir, f"{environment}_{algorithm}_cp__{steps}_steps.pt"))
+            if (iters and it >= iters) or since_best >= 50:
+                stop.fill_(1.0)
+        if distributed:
+            broadcast_policy(list(learner.net.state_dict().values()) + [stop], src=0)
         col.load_policy(learner.net.state_dict())
-        steps += b["rewards"].numel(); it += 1
-        if it % 10 == 0:
-            mean_ep = ep_sum / ep_cnt if ep_cnt else float("nan")
-            logger.info(f"iter {it:5d}  timesteps {steps/1e6:8.1f} M  reward/step {stats['mean_reward']:+.4f}  ep_rew_mean {mean_ep:9.2f}  "
-                        f"value_loss {stats['value_loss']:.4f}  fps {steps/(time.time()-t0)/1e6:.1f} M")
-            score = stats["mean_reward"]
-            if score > best:
-                best, since_best = score, 0
-                torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt"))
-            else:
-                since_best += 1
-            if ep_cnt and mean_ep >= threshold:
-                logger.info(f"Stopping training: mean episode reward {mean_ep:.1f} reached the threshold {threshold}"); break
-            ep_sum = ep_cnt = 0.0
-        if it % 40 == 0:                                     # CheckpointCallback (ref: main.py:227-232)
-            torch.save(learner.net.state_dict(), os.path.join(save_dir, f"{environment}_{algorithm}_cp__{steps}_steps.pt"))
-        if (iters and it >= iters) or since_best >= 50:
+        if stop.item() > 0:
             break
-    torch.save(learner.net.state_dict(), os.path.join(save_dir, "last_model.pt"))
-    logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best reward/step {best:+.4f}; models in {save_dir}")
+    if lead:
+        torch.save(learner.net.state_dict(), os.path.join(save_dir, "last_model.pt"))
+        logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best reward/step {best:+.4f}; models in {save_dir}")
+    if distributed:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def _rollout_policy(environment, algorithm, model_file, n, steps, show_io, show_i, record_path=None):

@@ -53,3 +53,16 @@ def test_cli_train_test_record(tmp_path, monkeypatch):
     assert r.exit_code == 0
     traj = np.load(tmp_path / "movies" / "Env01-v1_PPO.npz")["trajectory"]
     assert traj.shape == (3000, 13 + 12 + 15 + 6) and np.isfinite(traj).all()
+
+
+@pytest.mark.gpu
+def test_cli_train_distributed_code_path(tmp_path, monkeypatch):
+    """The multi-GPU branch of `train` (RCCL init, rollout gather to rank 0, policy + stop-flag broadcast, barrier) with a
+    one-rank group: what can be exercised on a one-GPU box; the N > 1 collective itself is covered over gloo on the CPU."""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("SO100_FORCE_DIST", "1"); monkeypatch.setenv("MASTER_PORT", "29577")
+    r = CliRunner().invoke(drv.cli, ["-a", "PPO", "train", "-e", "Env02-v1", "--envs", "512", "--iters", "12"], catch_exceptions=False)
+    assert r.exit_code == 0
+    assert (tmp_path / "models" / "Env02-v1_PPO" / "last_model.pt").is_file()
+    import torch.distributed as dist
+    assert not dist.is_initialized()
