@@ -69,7 +69,7 @@ class So100VecEnv(_VecEnvBase):
     metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
 
     def __init__(self, env_id="Env01-v1", num_envs=4096, device=None, flags=F_REFERENCE, seed=0, env_id_offset=0,
-                 solver_iters=2, contact_iters=6, max_episode_steps=None, stagger_episodes=False, full_infos=False):
+                 solver_iters=2, contact_iters=6, max_episode_steps=None, stagger_episodes=False, full_infos=False, use_graph=True):
         self.env_id = env_id
         self.kind = kind_from_id(env_id) if isinstance(env_id, str) else int(env_id)
         obs_space, act_space = make_spaces(self.kind)
@@ -87,6 +87,13 @@ class So100VecEnv(_VecEnvBase):
         self._h_rew = torch.empty(num_envs, dtype=torch.float32, pin_memory=True)
         self._h_done = torch.empty(num_envs, dtype=torch.uint8, pin_memory=True)
         self._h_trunc = torch.empty(num_envs, dtype=torch.uint8, pin_memory=True)
+        self._h_act = torch.zeros(num_envs, 6, dtype=torch.float32, pin_memory=True)
+        self._h_tobs = torch.empty(num_envs, od, dtype=torch.float32, pin_memory=True)
+        self._h_epr = torch.empty(num_envs, dtype=torch.float32, pin_memory=True)
+        self._h_epl = torch.empty(num_envs, dtype=torch.int32, pin_memory=True)
+        # the whole host round trip of one step -- actions H2D, the fused step kernel, results D2H -- is one hipGraph launch
+        # (captured on the second step; so100_step allocates nothing and never synchronises, include/so100_sim.h)
+        self._use_graph = use_graph; self._graph = None; self._eager_steps = 0
         self._dirty = []                                # infos filled on the previous step (cleared lazily)
         self._t0 = time.time()
         self.spec = type("Spec", (), {"id": K.ENV_IDS[self.kind], "max_episode_steps": self.sim.cfg.max_episode_steps,
@@ -110,13 +117,28 @@ class So100VecEnv(_VecEnvBase):
         return self.reset_tensor().cpu().numpy()
 
     def step_async(self, actions):
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 6))
-        self._actions.copy_(a, non_blocking=True)
+        self._h_act.numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 6)
 
-    def step_wait(self):
+    def _round_trip(self):
+        self._actions.copy_(self._h_act, non_blocking=True)
         obs, rew, done, trunc = self.sim.step(self._actions)
         self._h_obs.copy_(obs, non_blocking=True); self._h_rew.copy_(rew, non_blocking=True)
         self._h_done.copy_(done, non_blocking=True); self._h_trunc.copy_(trunc, non_blocking=True)
+        self._h_tobs.copy_(self.sim.terminal_obs, non_blocking=True)
+        self._h_epr.copy_(self.sim.ep_return, non_blocking=True); self._h_epl.copy_(self.sim.ep_length, non_blocking=True)
+
+    def step_wait(self):
+        if self._graph is not None:
+            self._graph.replay()
+        elif self._use_graph and self._eager_steps >= 1:
+            torch.cuda.current_stream(self.device).synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._round_trip()
+            self._graph = g
+            g.replay()                                   # capture records, it does not run
+        else:
+            self._round_trip(); self._eager_steps += 1
         torch.cuda.current_stream(self.device).synchronize()
         # fresh arrays every step: SB3 keeps `_last_obs` alive across the next env.step()
         obs_h = self._h_obs.numpy().copy(); rew_h = self._h_rew.numpy().copy()
@@ -127,8 +149,8 @@ class So100VecEnv(_VecEnvBase):
         if done_h.any():
             idx = np.nonzero(done_h)[0]
             trunc_h = self._h_trunc.numpy().astype(bool)
-            tobs = self.sim.terminal_obs[torch.as_tensor(idx, device=self.device)].cpu().numpy()
-            ep_r = self.sim.ep_return.cpu().numpy(); ep_l = self.sim.ep_length.cpu().numpy()
+            tobs = self._h_tobs.numpy()[idx].copy()
+            ep_r = self._h_epr.numpy(); ep_l = self._h_epl.numpy()
             t = round(time.time() - self._t0, 6)
             for j, i in enumerate(idx):
                 self._infos[i] = {"terminal_observation": tobs[j], "TimeLimit.truncated": bool(trunc_h[i]),
