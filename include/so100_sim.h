@@ -150,6 +150,8 @@ void so100_destroy(so100_sim* sim);
  * mask_dev: [N] bytes, non-zero = reset that env; NULL = all.  obs_dev rows of untouched envs are left alone. */
 int  so100_reset(so100_sim* sim, const uint8_t* mask_dev, const float* inject_dev, float* obs_dev, void* hip_stream);
 
+/* One launch: the 4-wave latency kernel for N <= 16384, the one-wave-per-64-envs throughput kernel above (results agree
+ * to the last bit or two; SO100_STEP_KERNEL=single in the environment at so100_create forces the latter). */
 int  so100_step(so100_sim* sim, const so100_step_io* io, void* hip_stream);
 
 /* ref: reads / writes of data.qpos, data.qvel (MjData), SoA: qpos_dev [13][N], qvel_dev [12][N] */

@@ -31,14 +31,124 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // -DSO100_ROLLOUT_PROF; the product library compiles these to nothing).  Slots: see tools/rollout_prof.py.
 #ifdef SO100_ROLLOUT_PROF
 __device__ long long so100_prof[32];
-#define SO100_PROF_DECL long long pt_[16] = {}; long long pc_ = __builtin_readcyclecounter();
-#define SO100_PROF(slot) do { const long long n_ = __builtin_readcyclecounter(); pt_[slot] += n_ - pc_; pc_ = n_; } while (0)
-#define SO100_PROF_FLUSH(base) do { if (blockIdx.x == 0 && lane == 0) for (int i_ = 0; i_ < 8; i_++) so100_prof[(base) + i_] = pt_[i_]; } while (0)
+struct Prof {
+    long long t[8] = {}, c = __builtin_readcyclecounter();
+    __device__ __forceinline__ void mark(int slot) { const long long n = __builtin_readcyclecounter(); t[slot] += n - c; c = n; }
+    __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 8; i++) so100_prof[base + i] = t[i]; }
+};
 #else
-#define SO100_PROF_DECL
-#define SO100_PROF(slot) do {} while (0)
-#define SO100_PROF_FLUSH(base) do {} while (0)
+struct Prof {
+    __device__ __forceinline__ void mark(int) {}
+    __device__ __forceinline__ void flush(int, bool) const {}
+};
 #endif
+#define SO100_PROF_DECL Prof prof_;
+#define SO100_PROF(slot) prof_.mark(slot)
+#define SO100_PROF_FLUSH(base) prof_.flush((base), blockIdx.x == 0 && lane == 0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// The 16 physics substeps of ONE env step for the 64 envs of a workgroup, split over its waves (all waves of the
+// workgroup must call this; env state of env = lane lives in wave 0's registers):
+//   wave 0: sin/cos, CRBA mass matrix + factorisation, then solve + integrate          wave 1: RNEA bias force
+//   wave 2: the cube's free-body / floor-contact substep (when it is simulated)         others: only the barriers
+// Two workgroup barriers per substep; sin/cos, q-dot, the bias force and the cube state cross through LDS.  Same
+// operations in the same order as physics_substeps(), so results agree with it to the last bit or two.  Used by the
+// persistent rollout kernel and by the multi-wave single-step kernel (so100_step_mw).  `after_first_barrier(sub)` lets
+// the caller hang work on an idle wave (the rollout kernel pre-draws the next step's policy noise on wave 3).
+// On return (wave 0): e.q/v/qc/ff/fl/cube updated, A.s / A.c = sin/cos the LAST substep started from, cstale = the
+// cube position it started from (Q1).
+// ---------------------------------------------------------------------------------------------------------------
+template <class Hook>
+__device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, const float ctrl[6], float cstale[3],
+                                                 Arm<float>& A, float (&xq)[18][64], float (&xc)[24][64], float (&xb)[6][64], Prof& prof_, Hook after_first_barrier) {
+    float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    // The cube is dynamically independent of the arm: when it is simulated (not pinned) wave 2 owns it for the
+    // substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
+    const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
+    Cube<float> cb; CubePrep<float> cprep;
+    float applied[3] = { 0.0f, 0.0f, 0.0f };
+    if (cube_live) {
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) xc[i][lane] = e.cube.pos[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) xc[3 + i][lane] = e.cube.quat[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xc[7 + i][lane] = e.cube.vel[i]; xc[13 + i][lane] = e.cube.warm[i]; }
+            xc[19][lane] = (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f;
+        }
+        __syncthreads();
+        if (wave == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) cb.pos[i] = xc[i][lane];
+#pragma unroll
+            for (int i = 0; i < 4; i++) cb.quat[i] = xc[3 + i][lane];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { cb.vel[i] = xc[7 + i][lane]; cb.warm[i] = xc[13 + i][lane]; }
+            applied[2] = xc[19][lane];
+        }
+    } else if (wave == 0) {
+        cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];      // kinematic cube
+    }
+#pragma unroll 1
+    for (int sub = 0; sub < p.frame_skip; sub++) {
+        if (wave == 0) {
+            // sin/cos: exact at the first substep, then rotated by the integration increment (arm_substep does the same)
+            if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
+            SO100_PROF(2);                                 // trig (wave 0)
+        }
+        __syncthreads();
+        SO100_PROF(3);                                     // barrier 1 wait
+        after_first_barrier(sub);
+        if (wave == 1) {
+            float v1[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { A.s[i] = xq[i][lane]; A.c[i] = xq[6 + i][lane]; v1[i] = xq[12 + i][lane]; }
+            arm_bias<float>(v1, A);
+#pragma unroll
+            for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
+            SO100_PROF(4);                                 // RNEA (wave 1)
+        } else if (wave == 0) {
+            arm_mass<float>(A);
+            arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
+            SO100_PROF(4);                                 // CRBA + factor (wave 0)
+        } else if (wave == 2 && cube_live) {
+            if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
+            cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
+            SO100_PROF(4);                                 // cube_prepare (wave 2)
+        }
+        __syncthreads();
+        SO100_PROF(5);                                     // barrier 2 wait
+        if (wave == 2 && cube_live) { cube_finish<float>(cb, p.flags, p.contact_iters, cprep); SO100_PROF(6); }   // ... Newton + Euler behind the arm's solve
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
+            arm_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
+            SO100_PROF(6);                                 // solve + integrate (wave 0)
+        }
+    }
+    if (cube_live) {
+        if (wave == 2) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) xc[i][lane] = cb.pos[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) xc[3 + i][lane] = cb.quat[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xc[7 + i][lane] = cb.vel[i]; xc[13 + i][lane] = cb.warm[i]; }
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { e.cube.pos[i] = xc[i][lane]; cstale[i] = xc[20 + i][lane]; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) e.cube.quat[i] = xc[3 + i][lane];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { e.cube.vel[i] = xc[7 + i][lane]; e.cube.warm[i] = xc[13 + i][lane]; }
+        }
+    }
+}
 
 // Policy hidden layers on the matrix cores: per tower and layer, H[64 envs][64 units] = tanh(X[64][K] W^T + b) is a genuine
 // contraction (K = 16 / 64).  v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain, so results are bit-compatible
@@ -196,98 +306,14 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
-            float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-            // The cube is dynamically independent of the arm: when it is simulated (not pinned) wave 2 owns it for the
-            // substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
-            const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
-            Cube<float> cb; CubePrep<float> cprep;
-            float applied[3] = { 0.0f, 0.0f, 0.0f };
-            if (cube_live) {
-                if (wave == 0) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) xc[i][lane] = e.cube.pos[i];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) xc[3 + i][lane] = e.cube.quat[i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { xc[7 + i][lane] = e.cube.vel[i]; xc[13 + i][lane] = e.cube.warm[i]; }
-                    xc[19][lane] = (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f;
-                }
-                __syncthreads();
-                if (wave == 2) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) cb.pos[i] = xc[i][lane];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) cb.quat[i] = xc[3 + i][lane];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { cb.vel[i] = xc[7 + i][lane]; cb.warm[i] = xc[13 + i][lane]; }
-                    applied[2] = xc[19][lane];
-                }
-            } else if (wave == 0) {
-                cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];      // kinematic cube
-            }
-#pragma unroll 1
-            for (int sub = 0; sub < p.frame_skip; sub++) {
-                if (wave == 0) {
-                    // sin/cos: exact at the first substep, then rotated by the integration increment (arm_substep does the same)
-                    if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
-                    SO100_PROF(2);                                 // trig (wave 0)
-                }
-                __syncthreads();
-                SO100_PROF(3);                                     // barrier 1 wait
+            physics_phase_mw(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
                     policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
 #pragma unroll
                     for (int a = 0; a < 6; a++) xn[a][lane] = eps[a];
                 }
-                if (wave == 1) {
-                    float v1[6];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { A.s[i] = xq[i][lane]; A.c[i] = xq[6 + i][lane]; v1[i] = xq[12 + i][lane]; }
-                    arm_bias<float>(v1, A);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
-                    SO100_PROF(4);                                 // RNEA (wave 1)
-                } else if (wave == 0) {
-                    arm_mass<float>(A);
-                    arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
-                    SO100_PROF(4);                                 // CRBA + factor (wave 0)
-                } else if (wave == 2 && cube_live) {
-                    if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
-                    cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
-                    SO100_PROF(4);                                 // cube_prepare (wave 2)
-                }
-                __syncthreads();
-                SO100_PROF(5);                                     // barrier 2 wait
-                if (wave == 2 && cube_live) { cube_finish<float>(cb, p.flags, p.contact_iters, cprep); SO100_PROF(6); }   // ... Newton + Euler behind the arm's solve
-                if (wave == 0) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
-                    arm_solve_integrate<float>(e.q, e.v, e.qc, ctx.ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
-                    SO100_PROF(6);                                 // solve + integrate (wave 0)
-                }
-            }
-            if (cube_live) {
-                if (wave == 2) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) xc[i][lane] = cb.pos[i];
-#pragma unroll
-                    for (int i = 0; i < 4; i++) xc[3 + i][lane] = cb.quat[i];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { xc[7 + i][lane] = cb.vel[i]; xc[13 + i][lane] = cb.warm[i]; }
-                }
-                __syncthreads();
-                if (wave == 0) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { e.cube.pos[i] = xc[i][lane]; cstale[i] = xc[20 + i][lane]; }
-#pragma unroll
-                    for (int i = 0; i < 4; i++) e.cube.quat[i] = xc[3 + i][lane];
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { e.cube.vel[i] = xc[7 + i][lane]; e.cube.warm[i] = xc[13 + i][lane]; }
-                }
-            }
+            });
             if (wave == 0) {
                 e.nsub += p.frame_skip;
                 TaskPoses<float> P;

@@ -100,6 +100,62 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
     }
 }
 
+// K1-mw: the same fused env step with a workgroup of 4 waves per 64 envs -- the physics of env = lane is split over the waves
+// exactly as in the persistent rollout kernel (physics_phase_mw: RNEA on wave 1, cube on wave 2, CRBA / solve on wave 0).
+// One env step then costs ~2/3 of the single-wave kernel's latency; it occupies 4 SIMDs per 64 envs, so it is the step
+// kernel for batches that do not fill the chip (launch_step picks it for N <= 16384) and so100_step_fused stays the
+// throughput kernel for large batches.
+template <int KIND, int FL>
+__global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
+    __shared__ float xq[18][64];
+    __shared__ float xc[24][64];
+    __shared__ float xb[6][64];
+    if (FL >= 0) p.flags = (unsigned)FL;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int env = blockIdx.x*64 + lane;
+    const bool live = env < p.n;
+    constexpr int OD = obs_dim<KIND>();
+    EnvState e; StepCtx ctx{}; float u[8] = {}; float cstale[3] = {};
+    const float* inj = (io.inject && live) ? io.inject + (size_t)env*SO100_NINJECT : nullptr;
+    if (wave == 0) {
+        if (live) load_env_state<KIND>(io.state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
+        float a[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) a[i] = live ? io.act[(size_t)env*6 + i] : 0.0f;
+        draw8(p, p.env_id_offset + (uint32_t)env, (uint32_t)e.rngc, 0, inj, u);
+        e.rngc++;
+        env_step_pre<KIND>(e, a, u, p, ctx);
+    }
+    Arm<float> A; Prof prof_;
+    physics_phase_mw(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, prof_, [](int) {});
+    if (wave != 0 || !live) return;
+    e.nsub += p.frame_skip;
+    TaskPoses<float> P;
+    task_poses<float>(A.s, A.c, !reach_kind<KIND>(), P);
+    float obs[OD], tobs[OD]; bool term;
+    const float reward = env_step_post<KIND>(e, ctx, u, P, cstale, obs, term);
+    const StepResult r = env_step_finish<KIND>(e, reward, term, p, p.env_id_offset + (uint32_t)env, inj, io.start_tab, obs, tobs);
+    store_env_state<KIND>(io.state, p.n, env, e);
+#pragma unroll
+    for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];
+    io.rew[env] = r.reward;
+    if (io.rollout_row) {
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 6] = r.reward;
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? 1.0f : 0.0f;
+    }
+    io.done[env] = r.done ? 1 : 0;
+    io.trunc[env] = r.trunc_only ? 1 : 0;
+    if (r.done) {
+        if (io.tobs) {
+#pragma unroll
+            for (int i = 0; i < OD; i++) io.tobs[(size_t)env*OD + i] = tobs[i];
+        }
+        if (io.ep_ret) io.ep_ret[env] = r.ep_return;
+        if (io.ep_len) io.ep_len[env] = r.ep_length;
+    }
+}
+
 // K2: masked reset (MujocoEnv.reset -> mj_resetData -> reset_model), SURVEY.md section 8a row a6
 template <int KIND>
 __global__ void __launch_bounds__(WG) so100_reset_masked(SimParams p, float* state, const float* start_tab,
@@ -149,6 +205,7 @@ struct so100_sim {
     SimParams prm;
     float* state = nullptr;        // [SF_COUNT][N]
     float* start_tab = nullptr;    // [36][6]
+    bool single_wave_step = false; // SO100_STEP_KERNEL=single in the environment at so100_create: always so100_step_fused (A/B knob for tools/)
 };
 
 namespace {
@@ -164,18 +221,20 @@ struct DeviceGuard {
 };
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
+constexpr int MW_MAX_ENVS = 16384;   // up to here the 4-wave step kernel wins (256 CUs x 64 envs); beyond, the chip is full anyway
+
 template <int KIND> int launch_step(so100_sim* s, const StepPtrs& io, hipStream_t st) {
-    const dim3 g = grid_for(s->prm.n), b(WG);
+    const bool mw = s->prm.n <= MW_MAX_ENVS && !s->single_wave_step;
+    const dim3 g = grid_for(s->prm.n), b(mw ? 256 : WG);
+#define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, s->prm, io); \
+                             else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, s->prm, io); } while (0)
     switch (s->prm.flags) {
-    case SO100_F_CUBE_PINNED:
-        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_CUBE_PINNED>), g, b, 0, st, s->prm, io); break;
-    case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED:
-        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED>), g, b, 0, st, s->prm, io); break;
-    case SO100_F_REFERENCE:
-        hipLaunchKernelGGL((so100_step_fused<KIND, SO100_F_REFERENCE>), g, b, 0, st, s->prm, io); break;
-    default:
-        hipLaunchKernelGGL((so100_step_fused<KIND, -1>), g, b, 0, st, s->prm, io); break;
+    case SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_CUBE_PINNED); break;
+    case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED); break;
+    case SO100_F_REFERENCE: SO100_STEP(SO100_F_REFERENCE); break;
+    default: SO100_STEP(-1); break;
     }
+#undef SO100_STEP
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }
@@ -245,6 +304,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         (void)hipFree(s->state); if (s->start_tab) (void)hipFree(s->start_tab); delete s;
         return fail(SO100_E_NOMEM, "so100_create: start table upload failed%s");
     }
+    { const char* kv = getenv("SO100_STEP_KERNEL"); s->single_wave_step = kv && strcmp(kv, "single") == 0; }
     const int rc = DISPATCH_KIND(cfg->env_kind, launch_init)(s);
     if (rc != 0) { (void)hipFree(s->state); (void)hipFree(s->start_tab); delete s; return rc; }
     *out = s;
