@@ -183,7 +183,12 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     // ---- once per launch: weight fragments -> registers, head weights -> LDS, env state -> registers, obs -> LDS
     const float* W1 = tower ? w.vf_w0 : w.pi_w0; const float* W2 = tower ? w.vf_w1 : w.pi_w1;
     const float* Bi1 = tower ? w.vf_b0 : w.pi_b0; const float* Bi2 = tower ? w.vf_b1 : w.pi_b1;
-    float bw1[2][ODP/2], bw2[2][32], b1v[2], b2v[2];
+    // Layer-2 B fragments: 64 VGPRs per lane, live through the whole physics phase.  The contact-disabled variant has the
+    // registers to spare; the constrained variants do not (they spilled to scratch), so there the fragments live in 64 KB of
+    // LDS [wave][column tile][k step][lane] and are read back right before each MFMA (measured: +3..4 % / -0.5 %).
+    constexpr bool W2_LDS = FL != (int)F_CUBE_PINNED;
+    float bw1[2][ODP/2], bw2[2][W2_LDS ? 1 : 32], b1v[2], b2v[2];
+    __shared__ float w2s[W2_LDS ? 4 : 1][2][32][W2_LDS ? 64 : 1];
 #pragma unroll
     for (int ct = 0; ct < 2; ct++) {
         const int unit = 32*ct + lj;
@@ -191,7 +196,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
 #pragma unroll
         for (int s2 = 0; s2 < ODP/2; s2++) { const int k = 2*s2 + lh; bw1[ct][s2] = k < OD ? W1[unit*OD + k] : 0.0f; }
 #pragma unroll
-        for (int s2 = 0; s2 < 32; s2++) bw2[ct][s2] = W2[unit*64 + 2*s2 + lh];
+        for (int s2 = 0; s2 < 32; s2++) { if constexpr (W2_LDS) w2s[wave][ct][s2][lane] = W2[unit*64 + 2*s2 + lh]; else bw2[ct][s2] = W2[unit*64 + 2*s2 + lh]; }
     }
     if (wave == NW - 1) {
         for (int i = lane; i < 6*64; i += 64) hd[i] = w.mu_w[i];
@@ -244,8 +249,10 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
 #pragma unroll
             for (int s2 = 0; s2 < 32; s2++) {
                 const float a = h1t[tower][32*rt + lj][2*s2 + lh];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[0][s2], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[1][s2], acc1, 0, 0, 0);
+                float b0, b1;
+                if constexpr (W2_LDS) { b0 = w2s[wave][0][s2][lane]; b1 = w2s[wave][1][s2][lane]; } else { b0 = bw2[0][s2]; b1 = bw2[1][s2]; }
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
