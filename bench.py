@@ -239,7 +239,7 @@ def main():
     # committed PMC pass (profiles/r01_c_pmc_summary.json, same workload / batch size) is quoted when it matches.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_h_pmc_summary.json" if args.policy == "persistent" else "r01_c_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_j_pmc_summary.json" if args.policy == "persistent" else "r01_c_pmc_summary.json")))
         if args.workload == "env01_free" and n == 4096:
             key = "rollout_fused" if args.policy == "persistent" else "step_fused"
             traffic = [v for k, v in pmc["kernels"].items() if key in k][0]["hbm_traffic_bytes_per_launch"]
