@@ -23,7 +23,8 @@ class RolloutCollector:
         self.counter = 0
         # one launch per chunk (so100_rollout: lowest latency, but one physics wave per CU => best up to 256 CUs x 64
         # envs) vs two launches per step (so100_policy_forward + so100_step: every lane computes physics => best
-        # throughput for large batches).  Measured on MI355X: 4096 envs 110 M vs 68 M env-steps/s; 65536 envs 0.44 G vs 1.0 G.
+        # throughput for large batches).  Measured on MI355X (profiles/r01_k_*): persistent 4096 envs 121 M, 16384 envs 478 M
+        # env-steps/s (34 us per step up to 256 workgroups = one per CU); stepwise 65536 envs 0.73 G, 1 M envs 1.33 G.
         self.persistent = (self.sim.n <= 16384) if persistent is None else persistent
         self.load_policy(state_dict)
         self._started = False

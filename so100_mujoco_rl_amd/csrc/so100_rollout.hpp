@@ -150,6 +150,145 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stand-alone policy forward on the matrix cores (the policy phase of the rollout kernel as its own launch): each
+// workgroup (4 waves) keeps its weight fragments in registers and walks over tiles of 64 envs (grid-stride), so the
+// weights are fetched once per workgroup, not once per 64 envs.  Same arithmetic as so100_rollout_fused's policy phase.
+// Replaces the VALU kernel so100_policy_forward_kernel as what so100_policy_forward launches (1 M envs: 961 -> see
+// profiles/): the VALU kernel re-staged 43 KB of weights per 64 envs and ran the 2 x 64 x (OD + 64) products at VALU rate.
+// ---------------------------------------------------------------------------------------------------------------
+template <int OD>
+__global__ void __launch_bounds__(256, 2) so100_policy_forward_mfma(int n, PolicyWeights w, PolicyIO io, uint32_t seed_lo, uint32_t seed_hi,
+                                                                 uint32_t env_id_offset, uint32_t step_counter) {
+    constexpr int ODP = (OD + 3) & ~3;
+    constexpr int LD = 65;
+    __shared__ __attribute__((aligned(16))) float hd[6*64 + 64 + 16];   // mu_w | v_w | mu_b(6) log_std(6) v_b(1)
+    __shared__ float oxt[64][ODP + 1];
+    __shared__ float h1t[2][64][LD];
+    __shared__ float h2t[2][64][LD];
+    __shared__ float xmean[6][64];
+    __shared__ float xn[6][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tower = wave >> 1, rt = wave & 1;
+    const int lj = lane & 31, lh = lane >> 5;
+    const float* W1 = tower ? w.vf_w0 : w.pi_w0; const float* W2 = tower ? w.vf_w1 : w.pi_w1;
+    const float* Bi1 = tower ? w.vf_b0 : w.pi_b0; const float* Bi2 = tower ? w.vf_b1 : w.pi_b1;
+    float bw1[2][ODP/2], bw2[2][32], b1v[2], b2v[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+        const int unit = 32*ct + lj;
+        b1v[ct] = Bi1[unit]; b2v[ct] = Bi2[unit];
+#pragma unroll
+        for (int s2 = 0; s2 < ODP/2; s2++) { const int k = 2*s2 + lh; bw1[ct][s2] = k < OD ? W1[unit*OD + k] : 0.0f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 32; s2++) bw2[ct][s2] = W2[unit*64 + 2*s2 + lh];
+    }
+    if (wave == 3) {
+        for (int i = lane; i < 6*64; i += 64) hd[i] = w.mu_w[i];
+        hd[6*64 + lane] = w.v_w[lane];
+        if (lane < 6) { hd[7*64 + lane] = w.mu_b[lane]; hd[7*64 + 6 + lane] = w.log_std[lane]; }
+        if (lane == 0) hd[7*64 + 12] = w.v_b[0];
+    }
+    for (int i = threadIdx.x; i < 64*(ODP + 1); i += 256) (&oxt[0][0])[i] = 0.0f;     // padding columns stay zero
+    const int ntiles = (n + 63)/64;
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int env = tile*64 + lane;
+        const bool live = env < n;
+        __syncthreads();                                            // previous tile fully consumed (and the zero fill / hd visible)
+        {   // the tile's observations: 64 x OD contiguous floats, loaded by all 256 threads
+            const size_t base = (size_t)tile*64*OD;
+            const int cnt = (n - tile*64 < 64 ? n - tile*64 : 64)*OD;
+            for (int i = threadIdx.x; i < 64*OD; i += 256) oxt[i / OD][i % OD] = i < cnt ? io.obs[base + i] : 0.0f;
+        }
+        __syncthreads();
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = b1v[0]; acc1[r] = b1v[1]; }
+#pragma unroll
+            for (int s2 = 0; s2 < ODP/2; s2++) {
+                const float a = oxt[32*rt + lj][2*s2 + lh];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw1[0][s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw1[1][s2], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32*rt + (r & 3) + 8*(r >> 2) + 4*lh;
+                h1t[tower][row][lj] = fast_tanh(acc0[r]); h1t[tower][row][32 + lj] = fast_tanh(acc1[r]);
+            }
+        }
+        __syncthreads();
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { acc0[r] = b2v[0]; acc1[r] = b2v[1]; }
+#pragma unroll
+            for (int s2 = 0; s2 < 32; s2++) {
+                const float a = h1t[tower][32*rt + lj][2*s2 + lh];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[0][s2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw2[1][s2], acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = 32*rt + (r & 3) + 8*(r >> 2) + 4*lh;
+                h2t[tower][row][lj] = fast_tanh(acc0[r]); h2t[tower][row][32 + lj] = fast_tanh(acc1[r]);
+            }
+        }
+        __syncthreads();
+        // heads: waves 0, 1, 3 two action means each; wave 2 the value head and the noise
+        if (wave != 2) {
+            const int a0 = wave == 0 ? 0 : (wave == 1 ? 2 : 4);
+            float m0 = hd[7*64 + a0], m1 = hd[7*64 + a0 + 1];
+#pragma unroll 4
+            for (int k = 0; k < 64; k += 4) {
+                const float x0 = h2t[0][lane][k], x1 = h2t[0][lane][k+1], x2 = h2t[0][lane][k+2], x3 = h2t[0][lane][k+3];
+                const float4 w0 = *reinterpret_cast<const float4*>(&hd[a0*64 + k]);
+                const float4 w1 = *reinterpret_cast<const float4*>(&hd[(a0 + 1)*64 + k]);
+                m0 = __builtin_fmaf(w0.x, x0, m0); m0 = __builtin_fmaf(w0.y, x1, m0); m0 = __builtin_fmaf(w0.z, x2, m0); m0 = __builtin_fmaf(w0.w, x3, m0);
+                m1 = __builtin_fmaf(w1.x, x0, m1); m1 = __builtin_fmaf(w1.y, x1, m1); m1 = __builtin_fmaf(w1.z, x2, m1); m1 = __builtin_fmaf(w1.w, x3, m1);
+            }
+            xmean[a0][lane] = m0; xmean[a0 + 1][lane] = m1;
+        } else {
+            float v = hd[7*64 + 12];
+#pragma unroll 8
+            for (int k = 0; k < 64; k++) v = __builtin_fmaf(hd[6*64 + k], h2t[1][lane][k], v);
+            if (live) {
+                if (io.value) io.value[env] = v;
+                if (io.rollout_row) io.rollout_row[(size_t)env*(OD + 10) + OD + 8] = v;
+            }
+            float eps[8];
+            if (io.noise) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) eps[a] = live ? io.noise[(size_t)env*6 + a] : 0.0f;
+            } else {
+                policy_noise(env_id_offset + (uint32_t)env, step_counter, seed_lo, seed_hi, eps);
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) xn[a][lane] = eps[a];
+        }
+        __syncthreads();
+        if (wave == 0 && live) {
+            float lp = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const float ls = hd[7*64 + 6 + a], e = xn[a][lane];
+                const float act = __builtin_fmaf(__builtin_expf(ls), e, xmean[a][lane]);
+                lp += -0.5f*e*e - ls - 0.9189385332046727f;
+                io.act_env[(size_t)env*6 + a] = tclamp(act, -1.0f, 1.0f);
+                if (io.act_raw) io.act_raw[(size_t)env*6 + a] = act;
+                if (io.rollout_row) io.rollout_row[(size_t)env*(OD + 10) + OD + a] = act;
+            }
+            if (io.logp) io.logp[env] = lp;
+            if (io.rollout_row) io.rollout_row[(size_t)env*(OD + 10) + OD + 9] = lp;
+        } else if (wave == 1 && live && io.rollout_row) {
+#pragma unroll
+            for (int k = 0; k < OD; k++) io.rollout_row[(size_t)env*(OD + 10) + k] = oxt[lane][k];
+        }
+    }
+}
+
 // Policy hidden layers on the matrix cores: per tower and layer, H[64 envs][64 units] = tanh(X[64][K] W^T + b) is a genuine
 // contraction (K = 16 / 64).  v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain, so results are bit-compatible
 // with the VALU policy kernel).  4 waves = one per SIMD: wave w owns tower w>>1, env rows [32(w&1), +32) and both 32-unit

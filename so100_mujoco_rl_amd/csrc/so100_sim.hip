@@ -350,13 +350,25 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
     memcpy(&pw, w, sizeof pw);
     PolicyIO pio; pio.obs = io->obs_dev; pio.noise = io->noise_dev; pio.act_env = io->act_env_dev; pio.act_raw = io->act_raw_dev;
     pio.value = io->value_dev; pio.logp = io->logp_dev; pio.rollout_row = io->rollout_row_dev;
-    const dim3 grid((unsigned)((s->prm.n + 63)/64));
+    // default: the matrix-core kernel, grid-stride over tiles of 64 envs, two workgroups per CU resident;
+    // SO100_POLICY_KERNEL=valu in the environment selects the older VALU kernel (A/B knob for tools/kbench_policy.py)
+    static const bool valu = []{ const char* e = getenv("SO100_POLICY_KERNEL"); return e && strcmp(e, "valu") == 0; }();
+    const int ntiles = (s->prm.n + 63)/64;
+    if (!valu) {
+        const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));
+        if (so100_obs_dim(s->cfg.env_kind) == 15)
+            hipLaunchKernelGGL((so100_policy_forward_mfma<15>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+        else
+            hipLaunchKernelGGL((so100_policy_forward_mfma<8>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+    } else {
+    const dim3 grid((unsigned)ntiles);
     static const int nw = []{ const char* e = getenv("SO100_POLICY_WAVES"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
 #define SO100_LAUNCH_POLICY(OD, NW) hipLaunchKernelGGL((so100_policy_forward_kernel<OD, NW>), grid, dim3(64*NW), 0, (hipStream_t)stream, \
         s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter)
     if (so100_obs_dim(s->cfg.env_kind) == 15) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
     else                      { if (nw == 4) SO100_LAUNCH_POLICY(8, 4);  else if (nw == 8) SO100_LAUNCH_POLICY(8, 8);  else SO100_LAUNCH_POLICY(8, 16); }
 #undef SO100_LAUNCH_POLICY
+    }
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }

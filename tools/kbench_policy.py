@@ -2,7 +2,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED
-n = 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 sim = So100Sim(1, n, flags=F_CUBE_PINNED); sim.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(0)
 r = lambda *s: (torch.randn(*s, device="cuda", generator=g) * 0.2).contiguous()
@@ -14,4 +14,4 @@ e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=T
 torch.cuda.synchronize(); e0.record()
 for i in range(200): sim.policy_forward(sim.obs, act, i, rollout_row=row)
 e1.record(); torch.cuda.synchronize()
-print(f"SO100_POLICY_WAVES={os.environ.get('SO100_POLICY_WAVES','16')}: policy kernel {e0.elapsed_time(e1)/200*1e3:.1f} us")
+print(f"N={n} SO100_POLICY_WAVES={os.environ.get('SO100_POLICY_WAVES','8')}: policy kernel {e0.elapsed_time(e1)/200*1e3:.1f} us")
