@@ -123,6 +123,11 @@ def main():
     ap.add_argument("--no-large-batch", action="store_true", help="skip the supplementary 1M-env kernel measurement")
     ap.add_argument("--policy", default="persistent", choices=["persistent", "fused", "torch"])
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when the
+    # first communicator is created), so file descriptor 1 points at stderr for the whole run and the result line is
+    # written to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1); os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -268,7 +273,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(kind, flags, 2)
         if world == 1 and args.workload == "env01_free" and not args.no_large_batch:
             out["roofline"]["large_batch"] = large_batch_roofline(kind, flags, dev)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
