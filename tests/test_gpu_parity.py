@@ -591,3 +591,28 @@ def test_stepwise_calls_are_graph_capturable():
         torch.cuda.synchronize()
         outs.append(torch.stack(rows))
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, REF), (5, REF), (2, ARM)])
+def test_multiwave_step_kernel_equals_single_wave(kind, flags, monkeypatch):
+    """so100_step picks the 4-wave latency kernel (so100_step_mw) for N <= 16384 and the one-wave throughput kernel above;
+    SO100_STEP_KERNEL=single (read at so100_create) forces the latter.  Same arithmetic, split over waves: results agree to
+    the last bit or two, including TimeLimit resets and the tail workgroup."""
+    n, steps = 200, 40
+    a_mw = _sim(kind, n, flags=flags, seed=9, max_episode_steps=15)
+    monkeypatch.setenv("SO100_STEP_KERNEL", "single")
+    a_sw = _sim(kind, n, flags=flags, seed=9, max_episode_steps=15)
+    monkeypatch.delenv("SO100_STEP_KERNEL")
+    o1 = a_mw.reset().clone(); o2 = a_sw.reset().clone()
+    assert torch.equal(o1, o2)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    lookat = kind >= 3 and kind <= 5
+    for t in range(steps):
+        act = torch.rand(n, 6, device="cuda", generator=g) * 2 - 1
+        r1 = [x.clone() for x in a_mw.step(act)]; r2 = [x.clone() for x in a_sw.step(act)]
+        torch.testing.assert_close(r1[0][:, :6], r2[0][:, :6], rtol=0, atol=2e-6)
+        torch.testing.assert_close(r1[0], r2[0], rtol=0, atol=6e-3 if lookat else 2e-6)     # look-at obs: integer pixel centres
+        torch.testing.assert_close(r1[1], r2[1], rtol=0, atol=2e-3 if lookat else 1e-5)
+        assert torch.equal(r1[2], r2[2]) and torch.equal(r1[3], r2[3])
+    q1, v1 = a_mw.get_state(); q2, v2 = a_sw.get_state()
+    torch.testing.assert_close(q1, q2, rtol=0, atol=2e-6); torch.testing.assert_close(v1, v2, rtol=0, atol=2e-5)
