@@ -1,6 +1,6 @@
 """Gymnasium single-env view (N = 1) of the batched simulator and the `register()` ids of the reference.
 
-ref: /root/reference/src/so100_mujoco_rl/__init__.py:5-38 registers Env01-v1 .. Env05-v1 (and Env06, out of scope) with
+ref: /root/reference/src/so100_mujoco_rl/__init__.py:5-45 registers Env01-v1 .. Env06-v1 with
 max_episode_steps 4000/6000 and reward_threshold 6000/8000.  `register_envs()` does the same for this package's entry
 point when gymnasium is importable (it is not in the build image; the class works without it).
 Step/reset signatures follow Gymnasium: reset(seed, options) -> (obs, info); step(a) -> (obs, reward, terminated,
@@ -10,35 +10,41 @@ import numpy as np
 import torch
 
 from . import constants as K
-from .lib import So100Sim, F_REFERENCE
-from .vec_env import make_spaces
+from .lib import F_REFERENCE
+from .vec_env import So100VecEnv, make_spaces
 
 
 class So100Env:
     metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
 
-    def __init__(self, env_kind=1, device=None, flags=F_REFERENCE, seed=0, render_mode=None, **kwargs):
+    def __init__(self, env_kind=1, device=None, flags=F_REFERENCE, seed=0, render_mode=None, max_episode_steps=None, **kwargs):
         self.kind = env_kind
         self.observation_space, self.action_space = make_spaces(env_kind)
-        self._mk = lambda s: So100Sim(env_kind, 1, device=device, flags=flags, seed=s, max_episode_steps=K.MAX_EPISODE_STEPS[env_kind])
-        self.sim = self._mk(seed)
+        # a one-env So100VecEnv underneath: its numpy round trip (pinned staging, one hipGraph launch, one sync per step)
+        self._mk = lambda s: So100VecEnv(env_kind, 1, device=device, flags=flags, seed=s,
+                                         max_episode_steps=K.MAX_EPISODE_STEPS[env_kind] if max_episode_steps is None else max_episode_steps)
+        self._v = self._mk(seed)
         self.render_mode = render_mode
+
+    @property
+    def sim(self):
+        return self._v.sim
 
     def reset(self, *, seed=None, options=None):
         if seed is not None:                            # unlike the reference (global np.random) seeding works
-            self.sim.close(); self.sim = self._mk(int(seed))
-        return self.sim.reset().cpu().numpy()[0].copy(), {}
+            self._v.close(); self._v = self._mk(int(seed))
+        return self._v.reset()[0].copy(), {}
 
     def step(self, action):
-        a = torch.as_tensor(np.asarray(action, np.float32).reshape(1, 6)).to(self.sim.device)
-        # a single env never auto-resets in Gymnasium: run the step, report, and let the caller reset
-        obs, rew, done, trunc = self.sim.step(a)
-        d = bool(done.item()); tr = bool(trunc.item())
-        ob = (self.sim.terminal_obs if d else obs).cpu().numpy()[0].copy()
-        return ob, float(rew.item()), d and not tr, tr, {}
+        # a single env never auto-resets in Gymnasium: run the step, report the terminal observation, and let the caller reset
+        self._v.step_async(np.asarray(action, np.float32).reshape(1, 6))
+        obs, rew, done, infos = self._v.step_wait()
+        d = bool(done[0]); tr = d and bool(infos[0].get("TimeLimit.truncated", False))
+        ob = infos[0]["terminal_observation"].copy() if d else obs[0]
+        return ob, float(rew[0]), d and not tr, tr, {}
 
     def close(self):
-        self.sim.close()
+        self._v.close()
 
     def render(self):
         return None

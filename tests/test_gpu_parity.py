@@ -524,6 +524,21 @@ def test_single_env_gym_view():
         total += r
     assert np.isfinite(total) and env.observation_space.shape == (15,)
     env.close()
+    # TimeLimit: the 4th step of a 4-step episode is truncated (not terminated) and reports the terminal observation
+    env = So100Env(1, flags=ARM, seed=5, max_episode_steps=4)
+    env.reset()
+    import time
+    for t in range(4):
+        ob, r, term, trunc, info = env.step(np.full(6, 0.3, np.float32))
+        assert term is False and trunc is (t == 3)
+    assert np.any(ob[6:] != 0)                                  # the terminal observation, not the all-zero-poses reset observation
+    ob0, _ = env.reset()
+    assert np.all(ob0[6:] == 0)
+    t0 = time.perf_counter()
+    for _ in range(300):
+        env.step(np.zeros(6, np.float32))
+    print(f"So100Env single-env step: {(time.perf_counter() - t0) / 300 * 1e6:.0f} us")
+    env.close()
 
 
 @pytest.mark.parametrize("kind,flags,n", [(1, FREE, 4096), (2, REF, 4096), (5, REF, 2048), (6, REF, 2048)])
