@@ -1,9 +1,12 @@
 """Plain-PyTorch PPO on top of the on-device rollout collector -- the learner used by `main.py train` when
 stable-baselines3 is not importable (it is not in this image).  Hyper-parameters are SB3's PPO defaults
 (ref: main.py:56-64 -> stable_baselines3.PPO("MlpPolicy")): 2x64 tanh towers, gamma 0.99, gae_lambda 0.95, clip 0.2,
-lr 3e-4, vf_coef 0.5, max_grad_norm 0.5; epochs 4 instead of 10 (the batch is 262 144 samples per update).
+lr 3e-4, vf_coef 0.5, max_grad_norm 0.5; epochs 4 instead of 10 (the batch is 262 144 samples per update).  On a GPU the
+update is replayed from two captured hipGraphs (GAE pass, minibatch step): it is launch-bound otherwise.
 The network's state_dict keys equal SB3's ActorCriticPolicy keys, so checkpoints and RolloutCollector.load_policy()
 interoperate with an SB3 policy."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -35,41 +38,94 @@ class ActorCritic(nn.Module):
 
 class PPO:
     def __init__(self, obs_dim, device, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip=0.2, epochs=4, minibatch=32768,
-                 vf_coef=0.5, max_grad_norm=0.5, seed=0):
+                 vf_coef=0.5, max_grad_norm=0.5, seed=0, use_graph=True):
         torch.manual_seed(seed)
         self.net = ActorCritic(obs_dim).to(device)
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, eps=1e-5)
+        on_gpu = torch.device(device).type == "cuda"
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, eps=1e-5, capturable=on_gpu)
         self.gamma, self.lam, self.clip, self.epochs, self.mb = gamma, gae_lambda, clip, epochs, minibatch
         self.vf_coef, self.max_grad_norm, self.device = vf_coef, max_grad_norm, device
+        # One PPO update is ~40 minibatch steps of ~100 tiny kernels each plus a 64-step GAE recursion: launch-bound in eager
+        # mode (~60 ms for a 262 144-sample batch).  With use_graph the GAE pass and the minibatch step are captured once as
+        # hipGraphs over static buffers and replayed (~5 ms); the arithmetic is the same.
+        self.use_graph = use_graph and on_gpu and os.environ.get("SO100_PPO_GRAPH", "1") != "0"
+        self._g = None
+
+    # ---- the two pieces of an update, written over the static buffers self._s (also what gets captured) ---------------
+    def _gae(self):
+        S = self._s; net = self.net
+        with torch.no_grad():
+            last_v = net.value(S["last_obs"])
+            T = S["rewards"].shape[0]
+            g = torch.zeros_like(last_v)
+            for t in reversed(range(T)):                       # GAE; dones[t] ends the episode after step t
+                nv = last_v if t == T - 1 else S["values"][t + 1]
+                nonterm = 1.0 - S["dones"][t]
+                delta = S["rewards"][t] + self.gamma * nv * nonterm - S["values"][t]
+                g = delta + self.gamma * self.lam * nonterm * g
+                S["adv"][t] = g
+            S["ret"].copy_((S["adv"] + S["values"]).reshape(-1))
+            a = S["adv"].reshape(-1)
+            S["adv_n"].copy_((a - a.mean()) / (a.std() + 1e-8))
+
+    def _step(self):
+        S = self._s; net = self.net; idx = S["idx"]
+        obs = S["obs"].reshape(-1, S["obs"].shape[-1]); act = S["actions"].reshape(-1, S["actions"].shape[-1])
+        v, lp = net.evaluate(obs.index_select(0, idx), act.index_select(0, idx))
+        adv = S["adv_n"].index_select(0, idx)
+        ratio = (lp - S["log_probs"].reshape(-1).index_select(0, idx)).exp()
+        pg = -torch.min(ratio * adv, ratio.clamp(1 - self.clip, 1 + self.clip) * adv).mean()
+        vl = (S["ret"].index_select(0, idx) - v).pow(2).mean()
+        loss = pg + self.vf_coef * vl
+        loss.backward()
+        nn.utils.clip_grad_norm_(net.parameters(), self.max_grad_norm); self.opt.step()
+        S["vl"].copy_(vl.detach())
+
+    def _alloc(self, b):
+        dev = self.device
+        self._s = {k: torch.empty(b[k].shape, dtype=torch.float32, device=dev) for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs")}
+        T, N = b["rewards"].shape
+        self._s.update(adv=torch.zeros(T, N, device=dev), ret=torch.zeros(T * N, device=dev), adv_n=torch.zeros(T * N, device=dev),
+                       idx=torch.zeros(min(self.mb, T * N), dtype=torch.long, device=dev), vl=torch.zeros((), device=dev))
+        self._shape = tuple(b["obs"].shape)
+
+    def _capture(self):
+        """torch's whole-network capture recipe: a few real steps on a side stream, then one captured step."""
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._gae()
+            for _ in range(3):
+                self.opt.zero_grad(set_to_none=True); self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        g_gae = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_gae):
+            self._gae()
+        g_step = torch.cuda.CUDAGraph(); self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(g_step):
+            self._step()
+        self._g = (g_gae, g_step)
 
     def update(self, b):
         """b: RolloutCollector.collect() output ([T, N, ...] device tensors + last_obs)."""
-        net = self.net
-        with torch.no_grad():
-            last_v = net.value(b["last_obs"])
-            T = b["rewards"].shape[0]
-            adv = torch.zeros_like(b["rewards"]); g = torch.zeros_like(last_v)
-            for t in reversed(range(T)):                       # GAE; dones[t] ends the episode after step t
-                nv = last_v if t == T - 1 else b["values"][t + 1]
-                nonterm = 1.0 - b["dones"][t]
-                delta = b["rewards"][t] + self.gamma * nv * nonterm - b["values"][t]
-                g = delta + self.gamma * self.lam * nonterm * g
-                adv[t] = g
-            ret = (adv + b["values"]).reshape(-1)
-            obs = b["obs"].reshape(-1, b["obs"].shape[-1]); act = b["actions"].reshape(-1, b["actions"].shape[-1])
-            oldlp = b["log_probs"].reshape(-1); adv = adv.reshape(-1)
-            adv = (adv - adv.mean()) / (adv.std() + 1e-8)
-        n = obs.shape[0]; vloss = 0.0
+        if getattr(self, "_s", None) is None or self._shape != tuple(b["obs"].shape):
+            self._alloc(b); self._g = None
+        S = self._s
+        for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
+            S[k].copy_(b[k])
+        n = S["ret"].numel(); mb = S["idx"].numel()
+        graph = self.use_graph and n % mb == 0
+        if graph and self._g is None:
+            S["idx"].copy_(torch.randperm(n, device=self.device)[:mb])
+            self._capture()
+        if graph: self._g[0].replay()
+        else: self._gae()
         for _ in range(self.epochs):
             perm = torch.randperm(n, device=self.device)
-            for i in range(0, n, self.mb):
-                idx = perm[i:i + self.mb]
-                v, lp = net.evaluate(obs[idx], act[idx])
-                ratio = (lp - oldlp[idx]).exp()
-                pg = -torch.min(ratio * adv[idx], ratio.clamp(1 - self.clip, 1 + self.clip) * adv[idx]).mean()
-                vl = (ret[idx] - v).pow(2).mean()
-                loss = pg + self.vf_coef * vl
-                self.opt.zero_grad(set_to_none=True); loss.backward()
-                nn.utils.clip_grad_norm_(net.parameters(), self.max_grad_norm); self.opt.step()
-                vloss = vl.item()
-        return {"value_loss": vloss, "mean_reward": b["rewards"].mean().item()}
+            for i in range(0, n, mb):
+                if graph:
+                    S["idx"].copy_(perm[i:i + mb]); self._g[1].replay()
+                else:
+                    S["idx"] = perm[i:i + mb]
+                    self.opt.zero_grad(set_to_none=True); self._step()
+        if not graph: S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
+        return {"value_loss": S["vl"].item(), "mean_reward": S["rewards"].mean().item()}
