@@ -631,3 +631,31 @@ def test_multiwave_step_kernel_equals_single_wave(kind, flags, monkeypatch):
         assert torch.equal(r1[2], r2[2]) and torch.equal(r1[3], r2[3])
     q1, v1 = a_mw.get_state(); q2, v2 = a_sw.get_state()
     torch.testing.assert_close(q1, q2, rtol=0, atol=2e-6); torch.testing.assert_close(v1, v2, rtol=0, atol=2e-5)
+
+
+def test_vecenv_graph_round_trip_equals_eager():
+    """So100VecEnv's numpy round trip is replayed from one captured hipGraph (actions H2D, step kernel, results D2H); the
+    replayed path must return exactly what the eager path returns, infos included, across TimeLimit resets."""
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    n = 300
+    eg = So100VecEnv("Env05-v1", n, flags=REF, seed=4, max_episode_steps=6, use_graph=True)
+    ee = So100VecEnv("Env05-v1", n, flags=REF, seed=4, max_episode_steps=6, use_graph=False)
+    np.testing.assert_array_equal(eg.reset(), ee.reset())
+    rs = np.random.RandomState(0)
+    for t in range(20):
+        a = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
+        og, rg, dg, ig = eg.step(a); oe, re_, de, ie = ee.step(a)
+        np.testing.assert_array_equal(og, oe); np.testing.assert_array_equal(rg, re_); np.testing.assert_array_equal(dg, de)
+        assert og.dtype == np.float32 and rg.dtype == np.float32 and dg.dtype == bool and og.shape == (n, 8)
+        for i in np.nonzero(dg)[0]:
+            assert ig[i]["TimeLimit.truncated"] == ie[i]["TimeLimit.truncated"] and ig[i]["episode"]["l"] == ie[i]["episode"]["l"] == 6
+            np.testing.assert_array_equal(ig[i]["terminal_observation"], ie[i]["terminal_observation"])
+            assert ig[i]["episode"]["r"] == ie[i]["episode"]["r"]
+        assert all(ig[i] == {} for i in np.nonzero(~dg)[0][:10])
+    assert eg._graph is not None and ee._graph is None
+    # mixing in the tensor API and a reset does not disturb the captured round trip
+    ot, _, _, _ = eg.step_tensor(torch.zeros(n, 6, device=eg.device)); ee.step_tensor(torch.zeros(n, 6, device=ee.device))
+    np.testing.assert_array_equal(eg.reset(), ee.reset())
+    a = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
+    np.testing.assert_array_equal(eg.step(a)[0], ee.step(a)[0])
+    eg.close(); ee.close()
