@@ -2,7 +2,7 @@
 t(step) = a + b * frame_skip  (a = policy + task layer + rollout-row traffic, b = one physics substep).  Needs a GPU.
     [SO100_LIB=...] python tools/kbench_rollout.py [envs]
 """
-import os, sys
+import gc, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
@@ -30,6 +30,6 @@ for kind, flags, name in [(1, F_CUBE_PINNED, "env01 free"), (1, F_FRICTIONLOSS |
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / reps / T * 1e3
         xs.append(fs); ys.append(us)
-        sim.close()
+        sim.close(); del sim, buf; gc.collect(); torch.cuda.synchronize()      # freeing buffers later would stall a timed loop
     b, a = np.polyfit(xs, ys, 1)
     print(f"{name:18s} N={n}  " + "  ".join(f"fs{f}:{y:6.2f}" for f, y in zip(xs, ys)) + f"  us/step   fit: a = {a:5.2f} us, b = {b:5.3f} us/substep", flush=True)
