@@ -3,11 +3,14 @@
 Run (build container only; /root/reference does not exist on the GPU box):
     python3 -B tests/golden/make_golden.py
 
-How: the reference's env classes (env01_v1.Env01, env02_v1.Env02, env05_v1.Env05, env06_v1.Env06) are imported
+How: the reference's env classes (env01_v1.Env01, env02_v1.Env02, env03_v1.Env03, env04_v1.Env04, env05_v1.Env05,
+env06_v1.Env06) are imported
 unmodified from /root/reference/src with the third-party modules that are not installed here
 (mujoco, gymnasium, glfw, cv2, ultralytics, PIL) replaced by stubs in sys.modules:
   * `MjData` is a thin named-accessor view over the oracle's fp64 `so100o_data` struct,
   * `mujoco.mj_step` calls the oracle's restatement of mj_step, `mj_resetData` its reset,
+  * `ultralytics.YOLO.track` (Env03 / Env04 only) returns ONE box: the reference's own get_projected_cube_bounding_box(),
+    over the black frame the stubbed offscreen renderer produces (the product's documented detector substitution),
   * `np.random.uniform/randint` are scripted so every draw is a recorded uniform u in [0,1)
     (numpy computes low + (high-low)*u, which the stub reproduces).
 So every line of reward / obs / ctrl / reset / curriculum / reprojection logic that executes is the
@@ -174,6 +177,7 @@ def install_stubs():
         O.lib().so100o_step(O.C.byref(model._m), O.C.byref(data._d), PHYS_FLAGS, 0, nstep)
     mj.mj_step = mj_step
     mj.mj_rnePostConstraint = lambda model, data: None     # results never read
+    mj.mjv_updateScene = mj.mjr_render = mj.mjr_readPixels = lambda *a, **k: None      # the offscreen image stays black
     mj.mj_resetData = lambda model, data: O.lib().so100o_reset_data(O.C.byref(model._m), O.C.byref(data._d))
     sys.modules["mujoco"] = mj
 
@@ -221,6 +225,10 @@ def install_stubs():
     class OffScreenViewer:
         def __init__(self, model, data, width, height):
             self.model = model; self.data = data
+            self.viewport = _Acc(width=width, height=height); self.vopt = self.scn = self.con = None
+
+        def make_context_current(self):
+            pass
     rendering.OffScreenViewer = OffScreenViewer
     registration = types.ModuleType("gymnasium.envs.registration")
     REGISTRY = []
@@ -238,7 +246,27 @@ def install_stubs():
     for name in ["glfw", "cv2", "PIL", "PIL.Image", "ultralytics"]:
         sys.modules[name] = types.ModuleType(name)
     sys.modules["PIL"].Image = sys.modules["PIL.Image"]
-    sys.modules["ultralytics"].YOLO = lambda path: None
+    glfw = sys.modules["glfw"]; glfw.get_current_context = lambda: None; glfw.make_context_current = lambda c: None
+    cv2 = sys.modules["cv2"]
+    cv2.line = cv2.rectangle = cv2.putText = lambda img, *a, **k: img
+    cv2.FONT_HERSHEY_SIMPLEX = 0; cv2.INTER_LINEAR = 1
+
+    class Detector:
+        """Stands in for ultralytics.YOLO in Env03 / Env04 (env_base_02.py:186-222): ONE box per frame, the reference's own
+        get_projected_cube_bounding_box() (env_base_02.py:154-176), confidence 0.9, track id 1, class 1; no box when that is None.
+        This is the documented detector substitution of the product; everything else in _get_obs / step is the reference's."""
+        names = {0: "other", 1: "cube"}
+        env = None
+
+        def __init__(self, path):
+            pass
+
+        def track(self, img, **kw):
+            assert img.shape == (1920, 1080, 3)
+            bb = self.env.get_projected_cube_bounding_box()
+            boxes = [] if bb is None else [_Acc(conf=[0.9], id=[1], cls=[1], xyxy=[[bb[0][0], bb[0][1], bb[1][0], bb[1][1]]])]
+            return [_Acc(boxes=boxes)]
+    sys.modules["ultralytics"].YOLO = Detector
     return REGISTRY
 
 
@@ -273,6 +301,8 @@ def main():
     from so100_mujoco_rl.envs.env02_v1 import Env02
     from so100_mujoco_rl.envs.env05_v1 import Env05
     from so100_mujoco_rl.envs.env06_v1 import Env06
+    from so100_mujoco_rl.envs.env03_v1 import Env03
+    from so100_mujoco_rl.envs.env04_v1 import Env04
     from so100_mujoco_rl.envs import env03_v1
 
     rs = np.random.RandomState(20240801)
@@ -354,6 +384,8 @@ def main():
     def run(EnvCls, kind, n_steps, seed, action_scale, episodes_reset_every=None, tweak=None):
         r2 = np.random.RandomState(seed)
         env = EnvCls()
+        if getattr(env, "yolo_model", None) is not None:
+            env.yolo_model.env = env
         steps = []
         inj = r2.random_sample(16).astype(np.float32)
         RNG.begin(inj); RNG.phase = 1
@@ -449,6 +481,18 @@ def main():
             ob2, _ = env.reset(); st["reset_after"] = True; st["reset_obs"] = f(ob2)
         rec["steps"].append(st)
     trajs.append(rec)
+    # Env03 / Env04 (appended last): the reference's step / reward / curriculum / _get_obs code with the detector stub above.
+    # A still arm (the cube wanders through the frame), a random run with resets, and a run that turns the camera away so
+    # that the lost-count branch (Env03: termination after > 30 lost steps; Env04: last centre re-used) fires.
+    def look_away(t, env, a):
+        a = np.zeros(6, np.float32); a[0] = 1.0 if t < 28 else 0.0
+        return a
+    trajs.append(run(Env03, 3, 80, 31, 0.0))
+    trajs.append(run(Env03, 3, 60, 32, 0.6, episodes_reset_every=25))
+    trajs.append(run(Env03, 3, 70, 33, 0.0, tweak=look_away))
+    trajs.append(run(Env04, 4, 80, 41, 0.0))
+    trajs.append(run(Env04, 4, 60, 42, 0.6, episodes_reset_every=25))
+    trajs.append(run(Env04, 4, 70, 43, 0.0, tweak=look_away))
     dump("trajectories.json", trajs)
     n_term = sum(s["terminated"] for tr in trajs for s in tr["steps"])
     n_reach = sum(1 for s in trajs[5]["steps"] if s.get("pre_teleport"))

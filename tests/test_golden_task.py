@@ -76,7 +76,7 @@ def test_projected_bounding_box(pure):
     assert n_box > 50 and n_none > 20
 
 
-@pytest.mark.parametrize("idx", range(9))
+@pytest.mark.parametrize("idx", range(15))
 def test_trajectory_replay(trajs, idx):
     """Reference Python over oracle physics == oracle C task layer over the same physics."""
     tr = trajs[idx]

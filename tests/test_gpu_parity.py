@@ -209,7 +209,7 @@ def test_device_rng_matches_oracle_philox():
         np.testing.assert_allclose(qpos[:, 5].cpu().numpy(), O.arr(e.d.qpos), rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("idx", range(9))
+@pytest.mark.parametrize("idx", range(15))
 def test_golden_trajectories_on_gpu(golden_dir, idx):
     """The trajectories recorded from the reference's own Python (over oracle physics) replayed on the HIP path."""
     tr = json.load(open(os.path.join(golden_dir, "trajectories.json")))[idx]
