@@ -270,6 +270,41 @@ def install_stubs():
     return REGISTRY
 
 
+def reference_cli_surface():
+    """The click surface of the reference's main.py (group options, commands, command options): imported with
+    stable_baselines3 stubbed (none of its classes is touched at import time)."""
+    import click
+    sb3 = types.ModuleType("stable_baselines3")
+    mods = {"stable_baselines3": sb3}
+    for sub, names in (("common", []), ("common.base_class", ["BaseAlgorithm"]),
+                       ("common.callbacks", ["StopTrainingOnNoModelImprovement", "StopTrainingOnRewardThreshold", "EvalCallback", "CheckpointCallback", "CallbackList"]),
+                       ("common.monitor", ["Monitor"]), ("common.noise", ["NormalActionNoise"]), ("common.vec_env", ["VecVideoRecorder", "DummyVecEnv"])):
+        m = types.ModuleType("stable_baselines3." + sub)
+        for n in names:
+            setattr(m, n, type(n, (), {}))
+        mods["stable_baselines3." + sub] = m
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    gym = sys.modules["gymnasium"]                       # (the stub of install_stubs) annotations / wrappers main.py names at import time
+    for n in ("Env", "Wrapper"):
+        if not hasattr(gym, n): setattr(gym, n, type(n, (), {}))
+    if not hasattr(gym, "wrappers"): gym.wrappers = types.SimpleNamespace(RecordVideo=type("RecordVideo", (), {}))
+    try:
+        import importlib
+        ref_main = importlib.import_module("so100_mujoco_rl.main")
+    finally:
+        for k, v in saved.items():
+            if v is None: sys.modules.pop(k, None)
+            else: sys.modules[k] = v
+
+    def params(cmd):
+        return [{"opts": sorted(p.opts), "required": bool(p.required), "is_flag": bool(getattr(p, "is_flag", False)),
+                 "default": p.default if isinstance(p.default, (str, int, float, bool, type(None))) else str(p.default)}
+                for p in cmd.params if isinstance(p, click.Option)]
+    return {"group": params(ref_main.cli), "commands": {name: params(c) for name, c in sorted(ref_main.cli.commands.items())},
+            "dirs": [ref_main.MODEL_DIR, ref_main.LOG_DIR, ref_main.RECORDING_DIR]}
+
+
 def f(x):
     """json-able float/array"""
     if isinstance(x, (list, tuple)):
@@ -321,6 +356,7 @@ def main():
         "obs_space_8": {"low": f(e5.observation_space.low), "high": f(e5.observation_space.high)},
         "action_space": {"low": f(e1.action_space.low), "high": f(e1.action_space.high)},
         "frame_skip": e1.frame_skip, "render_fps": Env01.metadata["render_fps"],
+        "cli": reference_cli_surface(),
     }
     dump("meta.json", meta)
 

@@ -23,6 +23,28 @@ def test_cli_surface(tmp_path, monkeypatch):
     assert "--show-io" in r.output and "--show-i" in r.output
 
 
+def test_cli_covers_the_reference_surface(golden_dir):
+    """meta.json["cli"] is the click surface of the reference's main.py, recorded by tests/golden/make_golden.py: every group
+    option, command and command option of the reference exists here with the same flags, required-ness and default."""
+    import json
+    import click
+    ref = json.load(open(os.path.join(golden_dir, "meta.json")))["cli"]
+
+    def opts(cmd):
+        return {tuple(sorted(p.opts)): p for p in cmd.params if isinstance(p, click.Option)}
+    mine = opts(drv.cli)
+    for o in ref["group"]:
+        p = mine[tuple(o["opts"])]
+        assert bool(p.required) == o["required"] and p.default == o["default"]
+    assert set(ref["commands"]) <= set(drv.cli.commands)
+    for name, ref_opts in ref["commands"].items():
+        mine = opts(drv.cli.commands[name])
+        for o in ref_opts:
+            p = mine[tuple(o["opts"])]
+            assert bool(p.required) == o["required"] and bool(p.is_flag) == o["is_flag"]
+    assert ref["dirs"] == [drv.MODEL_DIR, drv.LOG_DIR, drv.RECORDING_DIR]
+
+
 def test_cli_errors(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     if not drv._have_sb3():
