@@ -357,6 +357,9 @@ def main():
         "action_space": {"low": f(e1.action_space.low), "high": f(e1.action_space.high)},
         "frame_skip": e1.frame_skip, "render_fps": Env01.metadata["render_fps"],
         "cli": reference_cli_surface(),
+        "spaces": {str(k): {"obs_low": f(e.observation_space.low), "obs_high": f(e.observation_space.high),
+                            "act_low": f(e.action_space.low), "act_high": f(e.action_space.high)}
+                   for k, e in ((1, e1), (2, Env02()), (3, Env03()), (4, Env04()), (5, e5), (6, Env06()))},
     }
     dump("meta.json", meta)
 

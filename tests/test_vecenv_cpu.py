@@ -22,6 +22,10 @@ def test_spaces_match_reference(meta):
     np.testing.assert_array_equal(a.low, np.array(meta["action_space"]["low"], np.float32))
     np.testing.assert_array_equal(a.high, np.array(meta["action_space"]["high"], np.float32))
     assert o15.shape == (15,) and o8.shape == (8,) and a.shape == (6,) and o15.dtype == np.float32
+    for kind in range(1, 7):                                 # every registered env's own spaces (meta.json "spaces")
+        ref = meta["spaces"][str(kind)]; o, a = make_spaces(kind)
+        np.testing.assert_array_equal(o.low, np.array(ref["obs_low"], np.float32)); np.testing.assert_array_equal(o.high, np.array(ref["obs_high"], np.float32))
+        np.testing.assert_array_equal(a.low, np.array(ref["act_low"], np.float32)); np.testing.assert_array_equal(a.high, np.array(ref["act_high"], np.float32))
 
 
 def test_ids_limits_constants_match_reference(meta):
