@@ -1,0 +1,31 @@
+"""Long soak of the default rollout path: reference physics, staggered episodes, random policy; checks every chunk for
+non-finite values, the non-finite guard's latch, counters and device memory growth.   python tools/soak.py [seconds] [envs] [env_id]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from so100_mujoco_rl_amd.vec_env import So100VecEnv
+from so100_mujoco_rl_amd.collector import RolloutCollector
+from so100_mujoco_rl_amd.lib import F_REFERENCE
+
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+env_id = sys.argv[3] if len(sys.argv) > 3 else "Env05-v1"
+env = So100VecEnv(env_id, n, flags=F_REFERENCE, seed=0, stagger_episodes=True)
+sd = RolloutCollector.random_policy_state(env.sim.obs_dim, env.device)
+sd["log_std"] = sd["log_std"] + 0.5                          # a wilder policy than the initial one
+col = RolloutCollector(env, sd, T=64)
+col.collect(); torch.cuda.synchronize()
+mem0 = torch.cuda.memory_allocated(); t0 = time.time(); steps = 0; episodes = 0; chunks = 0; last = t0
+while time.time() - t0 < secs:
+    b = col.collect(); chunks += 1; steps += 64 * n
+    ok = bool(torch.isfinite(b["obs"]).all() & torch.isfinite(b["rewards"]).all() & torch.isfinite(b["values"]).all() & torch.isfinite(b["log_probs"]).all())
+    episodes += int((b["dones"] > 0).sum())
+    assert ok, f"non-finite value in chunk {chunks}"
+    if time.time() - last > 15:
+        last = time.time(); print(f"  {time.time()-t0:5.0f} s  {steps/1e9:6.2f} G env-steps  {episodes} episodes", flush=True)
+grow = torch.cuda.memory_allocated() - mem0                 # (before the queries below allocate their outputs)
+qpos, qvel = env.sim.get_state()
+bad = int(env.sim.bad_state_mask().sum())
+print(f"{env_id} x {n}: {steps/1e9:.2f} G env-steps in {time.time()-t0:.0f} s ({steps/(time.time()-t0)/1e6:.0f} M/s), {episodes} episodes, bad-state envs {bad}, "
+      f"state finite {bool(torch.isfinite(qpos).all() & torch.isfinite(qvel).all())}, max |qvel| {float(qvel.abs().max()):.1f}, device memory growth {grow} B")
+assert bad == 0 and grow == 0
