@@ -361,13 +361,11 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
         else
             hipLaunchKernelGGL((so100_policy_forward_mfma<8>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
     } else {
-    const dim3 grid((unsigned)ntiles);
-    static const int nw = []{ const char* e = getenv("SO100_POLICY_WAVES"); const int v = e ? atoi(e) : 8; return (v == 4 || v == 8 || v == 16) ? v : 8; }();
-#define SO100_LAUNCH_POLICY(OD, NW) hipLaunchKernelGGL((so100_policy_forward_kernel<OD, NW>), grid, dim3(64*NW), 0, (hipStream_t)stream, \
-        s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter)
-    if (so100_obs_dim(s->cfg.env_kind) == 15) { if (nw == 4) SO100_LAUNCH_POLICY(15, 4); else if (nw == 8) SO100_LAUNCH_POLICY(15, 8); else SO100_LAUNCH_POLICY(15, 16); }
-    else                      { if (nw == 4) SO100_LAUNCH_POLICY(8, 4);  else if (nw == 8) SO100_LAUNCH_POLICY(8, 8);  else SO100_LAUNCH_POLICY(8, 16); }
-#undef SO100_LAUNCH_POLICY
+        const dim3 grid((unsigned)ntiles);
+        if (so100_obs_dim(s->cfg.env_kind) == 15)
+            hipLaunchKernelGGL((so100_policy_forward_kernel<15, 8>), grid, dim3(512), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+        else
+            hipLaunchKernelGGL((so100_policy_forward_kernel<8, 8>), grid, dim3(512), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
     }
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
