@@ -31,7 +31,7 @@ for sub in ("sq", "fetch", "write"):
 out = {"note": "rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over `python bench.py --steps 256 --warmup 64 "
                "--no-cpu-baseline` on one MI355X; per-dispatch averages. FETCH_SIZE / WRITE_SIZE in KB; no gfx950 x2 correction applied "
                "(dword-per-lane accesses, an uncalibrated width); the x2 value is given alongside.",
-       "workload": f"env01_free, {N} envs, T = {T} steps per launch", "kernels": {}}
+       "workload": (sys.argv[2] if len(sys.argv) > 2 else "env01_free") + f", {N} envs, T = {T} steps per launch", "kernels": {}}
 for k, c in acc.items():
     d = {name: sum(v) / len(v) for name, v in c.items()}
     d["dispatches"] = {name: len(v) for name, v in c.items()}
