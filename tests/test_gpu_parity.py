@@ -659,3 +659,31 @@ def test_vecenv_graph_round_trip_equals_eager():
     a = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
     np.testing.assert_array_equal(eg.step(a)[0], ee.step(a)[0])
     eg.close(); ee.close()
+
+
+@pytest.mark.parametrize("n,frame_skip", [(1, 16), (63, 5), (65, 1), (130, 7)])
+def test_odd_batch_sizes_and_frame_skips_vs_oracle(n, frame_skip):
+    """Tail workgroups (N not a multiple of 64, N = 1) and frame_skip values other than the reference's 16, against the oracle."""
+    rs = np.random.RandomState(n)
+    sim = _sim(2, n, flags=REF, solver_iters=4, contact_iters=6, max_episode_steps=9, seed=5, frame_skip=frame_skip)
+    orc = [O.OracleEnv(2, flags=REF, iters=0, seed=5, env_id=i) for i in range(n)]
+    for e in orc:
+        e.e.max_episode_steps = 9; e.e.frame_skip = frame_skip
+    inj = rs.random_sample((n, 16)).astype(np.float32)
+    og = sim.reset(inject=torch.from_numpy(inj).cuda()).cpu().numpy()
+    oo = np.stack([e.reset(inject=inj[i]) for i, e in enumerate(orc)])
+    np.testing.assert_allclose(og, oo, rtol=0, atol=1e-6)
+    for t in range(20):
+        a = rs.uniform(-1, 1, (n, 6)).astype(np.float32); inj = rs.random_sample((n, 16)).astype(np.float32)
+        og, rg, dg, tg = sim.step(torch.from_numpy(a).cuda(), inject=torch.from_numpy(inj).cuda())
+        res = [e.step(a[i], inject=inj[i], autoreset=True) for i, e in enumerate(orc)]
+        np.testing.assert_allclose(og.cpu().numpy(), np.stack([r[0] for r in res]), rtol=0, atol=2e-5, err_msg=f"step {t}")
+        np.testing.assert_allclose(rg.cpu().numpy(), np.array([r[1] for r in res]), rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(dg.cpu().numpy().astype(bool), np.array([r[2] or r[3] for r in res]))
+    # and the rollout kernel on the same odd sizes: finite, right shape, TimeLimit fires
+    from so100_mujoco_rl_amd.collector import RolloutCollector, SB3_STATE_DICT_KEYS, POLICY_TENSORS
+    sd = RolloutCollector.random_policy_state(sim.obs_dim, sim.device, seed=0)
+    sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
+    buf = torch.zeros(12, n, sim.obs_dim + 10, device="cuda")
+    sim.rollout(buf, 0)
+    assert torch.isfinite(buf).all() and float(buf[..., -3].sum()) >= n
