@@ -5,15 +5,23 @@ One "step" = one vectorised env step of the rollout loop on every rank: policy f
 separate 2x64 tanh towers for pi and V, state-independent log-std Gaussian), action sampling + clipping, the fused
 HIP env step (reward -> ctrl -> 16 physics substeps -> obs -> TimeLimit -> auto-reset), and the write of
 obs/action/reward/done/value/log-prob into the on-device rollout buffer; every ROLLOUT_T steps the rollout chunk is
-gathered to the learner rank over RCCL (N > 1 only).  Default collector (`--policy persistent`): ONE launch per rollout chunk of 64 steps (so100_rollout: persistent
-workgroups, policy phase on all waves, physics phase on wave 0, env state in registers, weights in LDS).
-`--policy fused`: two launches per step (so100_policy_forward + so100_step), no PyTorch op in the loop.
-`--policy torch`: the same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).
---steps / --warmup count vectorised env steps in every mode (a trailing partial chunk is one shorter launch).  Workload = BASELINE.json configs[1]: Env01, 4096 envs per
-GPU, contact disabled / no constraint solver (cube pinned), synthetic randomized-reset batches, random-init policy.
+gathered to the learner rank over RCCL (N > 1 only).  Default collector (`--policy persistent`): ONE launch per rollout
+chunk of 64 steps (so100_rollout_fused: persistent workgroups, policy phase on all waves, physics split over the waves,
+env state in registers).  `--policy fused`: two launches per step (so100_policy_forward + so100_step), no PyTorch op in
+the loop.  `--policy torch`: the same rollout with the policy as plain PyTorch ops (what an unmodified SB3 policy costs).
+--steps / --warmup count vectorised env steps in every mode (a trailing partial chunk is one shorter launch).
+Default workload = BASELINE.json configs[1]: Env01, 4096 envs per GPU, contact disabled / no constraint solver (cube
+pinned), synthetic randomized-reset batches, random-init policy.  `--workload env01_contact` = configs[4]'s per-GPU shape.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (so100_step_fused) with the algorithmic
-452 B/env-step of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a port, not the reference) on the host cores.
+`python bench.py --gpus N` launches the N ranks itself (torch.distributed.run, one process per GPU, RCCL) when it is not
+already running under a launcher (WORLD_SIZE unset) and relays rank 0's line; under a launcher it is a rank.
+
+Prints ONE JSON line (rank 0).  The timed region of exactly --steps steps is repeated (`repeats`) and `value` is the
+MEDIAN repeat (min / max alongside): one 0.7 ms launch is not a measurement.  `roofline` prices the dominant kernel
+(so100_rollout_fused in the default mode) with the algorithmic 452 B/env-step of SURVEY.md section 8(d), its duration
+measured live with HIP events around every launch of the timed repeats; `cpu_baseline` times the CPU oracle (a port,
+not the reference) on the host cores; `sb3_vecenv_path` is the numpy-in / numpy-out `So100VecEnv.step` round trip that an
+unmodified SB3 learner drives (ref: main.py:57-63, 234-238), same batch, same physics flags, same run.
 """
 import argparse
 import json
@@ -28,6 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_ENV_STEP = 452.0        # SURVEY.md section 8(d), Env01, fp32 SoA, 16 substeps fused
+# SURVEY.md section 8(d) per env kind: Env02 500 B, Env05 536 B, contact configs ~600 B (key: (kind, pad contacts on))
+BYTES_PER_ENV_STEP_BY_KIND = {(1, False): 452.0, (2, False): 500.0, (5, False): 536.0, (1, True): 600.0, (2, True): 648.0, (5, True): 684.0}
+CONTACT_BITS = 16 | 32            # SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE (include/so100_sim.h)
 FLOP_PER_ENV_STEP_SURVEY = 6.0e4  # SURVEY.md section 8(d) estimate, constraint-free
 # measured: PMC SQ_INSTS_VALU = 22.95 k VALU instructions per env-step lane (profiles/r01_c), of which ~45 % are FMAs
 # (ISA count: 1017 fma/fmac of 2100 float ops per substep) => ~1.45 FLOP per instruction => 3.3e4 FLOP per env-step.
@@ -36,6 +47,15 @@ FLOP_PER_ENV_STEP = 3.3e4
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured achievable)
 VALU_PEAK_TFLOPS = 157.3
 ROLLOUT_T = 64
+# name -> (env kind, physics flag names, description); flags are resolved against so100_mujoco_rl_amd.lib at run time
+WORKLOADS = {
+    "env01_free": (1, ("F_CUBE_PINNED",), "contact disabled, no constraint solver (BASELINE.json configs[1])"),
+    "env01_arm": (1, ("F_FRICTIONLOSS", "F_LIMITS", "F_CUBE_PINNED"), "friction-loss + joint-limit rows, cube pinned"),
+    "env01_reference": (1, ("F_REFERENCE",), "reference physics: friction-loss + limits + cube/floor + pad/floor contact"),
+    "env02_reference": (2, ("F_REFERENCE",), "reference physics (BASELINE.json configs[2] at this batch size)"),
+    "env05_reference": (5, ("F_REFERENCE",), "reference physics (BASELINE.json configs[3] per-GPU shape)"),
+    "env01_contact": (1, ("F_CONTACT5",), "reference physics + finger-pad/cube box-box contact, coupled arm+cube solve (BASELINE.json configs[4] per-GPU shape)"),
+}
 
 
 class MlpPolicy:
@@ -84,8 +104,59 @@ def cpu_baseline(kind, flags, iters, seconds=12.0):
     while time.perf_counter() - t0 < seconds:
         b.step(acts, threads=threads); steps += 1
     dt = time.perf_counter() - t0
-    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
-            "sample": f"{n} Env01 envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads, same flags/solver iterations"}
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "host_cpus": cores, "kind": "port",
+            "sample": f"{n} Env{kind:02d} envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads on a {cores}-CPU host, same flags/solver iterations"}
+
+
+def sb3_vecenv_path(kind, flags, n, dev, steps=200):
+    """The SB3-facing path (ref: main.py:57-63 hands the env to SB3, whose collect_rollouts calls VecEnv.step with numpy
+    actions): So100VecEnv.step = H2D actions + fused step kernel + D2H results as one hipGraph + the Python info
+    bookkeeping.  Same batch size and physics flags as the headline, policy not included (SB3 runs its own)."""
+    import numpy as np
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    env = So100VecEnv(kind, n, device=dev, flags=flags, seed=77, stagger_episodes=True)
+    env.reset()
+    a = np.random.RandomState(1).uniform(-1, 1, (n, 6)).astype(np.float32)
+    for _ in range(20):
+        env.step(a)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.step(a)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "envs": n, "steps": steps,
+            "what": "So100VecEnv.step(numpy actions) -> numpy obs/rew/done/infos, one hipGraph per step, no policy"}
+
+
+def source_sha16():
+    """Fingerprint of the kernel sources: the committed PMC pass is only quoted while it describes THIS code."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "so100_mujoco_rl_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".h", ".inc")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(n_gpus, argv, worker=None, port=None):
+    """Start n_gpus fresh rank processes (torch.distributed.run, one per GPU) BEFORE this process touches the GPU and
+    relay rank 0's JSON line.  Returns the children's exit code."""
+    import socket
+    import subprocess
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), worker or os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    if proc.returncode == 0 and lines:
+        print(lines[-1], flush=True)
+    else:
+        sys.stderr.write(proc.stdout)
+    return proc.returncode if proc.returncode != 0 else (0 if lines else 1)
 
 
 def large_batch_roofline(kind, flags, dev, n=1 << 20, reps=20):
@@ -118,11 +189,22 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--workload", default="env01_free", choices=["env01_free", "env01_arm", "env01_reference", "env02_reference", "env05_reference"])
+    ap.add_argument("--workload", default="env01_free", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-large-batch", action="store_true", help="skip the supplementary 1M-env kernel measurement")
+    ap.add_argument("--no-sb3-path", action="store_true", help="skip the So100VecEnv numpy round-trip measurement")
+    ap.add_argument("--repeats", type=int, default=0, help="repeats of the timed region (0 = as many as fit ~1.5 s, 3..40)")
     ap.add_argument("--policy", default="persistent", choices=["persistent", "fused", "torch"])
+    ap.add_argument("--worker", default=None, help=argparse.SUPPRESS)      # script the launcher starts (tests use a stub)
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under a launcher: start the ranks ourselves, before anything here initialises the GPU
+        argv = [a for a in sys.argv[1:]]
+        sys.exit(launch_ranks(args.gpus, argv, worker=args.worker))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
     # The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a version banner when the
     # first communicator is created), so file descriptor 1 points at stderr for the whole run and the result line is
     # written to the saved descriptor at the end.
@@ -142,9 +224,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE, F_FRICTIONLOSS, F_LIMITS
-    kind, flags = {"env01_free": (1, F_CUBE_PINNED), "env01_arm": (1, F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED), "env01_reference": (1, F_REFERENCE),
-                   "env02_reference": (2, F_REFERENCE), "env05_reference": (5, F_REFERENCE)}[args.workload]
+    from so100_mujoco_rl_amd import lib as so100lib
+    from so100_mujoco_rl_amd.lib import So100Sim
+    kind, flag_names, wl_desc = WORKLOADS[args.workload]
+    flags = 0
+    for fn in flag_names:
+        flags |= getattr(so100lib, fn)
+    rccl_ranks = 1
+    if use_dist:                                             # the communicator really spans `world` ranks
+        ones = torch.ones(1, device=dev); dist.all_reduce(ones); rccl_ranks = int(ones.item())
+        assert rccl_ranks == world, (rccl_ranks, world)
     n = args.envs
     sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=2, contact_iters=6, seed=1234 + rank, env_id_offset=rank * n)
     obs = sim.reset()
@@ -170,7 +259,9 @@ def main():
                         "v_w": pol.v[0].t().contiguous(), "v_b": pol.v[1]})
     counter = [0]
 
-    def run(nsteps):
+    kev = []                                                 # (start, end, env-steps) HIP event pairs around the dominant kernel's launches
+
+    def run(nsteps, record=False):
         """exactly nsteps vectorised env steps, in rollout chunks of at most T steps"""
         ci = 0
         for c0 in range(0, nsteps, T):
@@ -180,13 +271,21 @@ def main():
                 pending[ci].wait(); pending[ci] = None
             chunk = chunks[ci][:Tc]
             if args.policy == "persistent":
+                if record:                                   # events on the launch stream (torch's current stream = where the C ABI enqueues)
+                    ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
                 sim.rollout(chunk, counter[0]); counter[0] += Tc               # ONE launch for Tc steps
+                if record:
+                    eb.record(); kev.append((ea, eb, n * Tc))
             else:
                 for t in range(Tc):
                     row = chunk[t]
                     if args.policy == "fused":
                         sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
+                        if record:
+                            ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
                         sim.step(act, rollout_row=row)                                     # reward | done -> row
+                        if record:
+                            eb.record(); kev.append((ea, eb, n))
                         counter[0] += 1
                     else:
                         noise.normal_(generator=g)
@@ -194,7 +293,11 @@ def main():
                         row[:, :sim.obs_dim] = sim.obs
                         row[:, sim.obs_dim:sim.obs_dim + 6] = a
                         a = a.clamp_(-1.0, 1.0)
+                        if record:
+                            ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
                         ob, rew, done, trunc = sim.step(a)
+                        if record:
+                            eb.record(); kev.append((ea, eb, n))
                         row[:, -4] = rew; row[:, -3] = done; row[:, -2] = value; row[:, -1] = logp
             if use_dist:
                 # RCCL: rollout chunk -> learner rank.  The collective is ordered after the producing kernel on this
@@ -209,66 +312,86 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    run(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+    def timed(record):
+        """EXACTLY args.steps steps between two {barrier + device synchronize}; max over ranks"""
+        sync()
+        t0 = time.perf_counter()
+        run(args.steps, record)
+        sync()
+        dt_own = time.perf_counter() - t0
+        dt = dt_own
+        if use_dist:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt.item())
+        return dt, dt_own
 
-    # dominant kernel alone: HIP events on the launch stream (torch's current stream, where the C ABI enqueues) around
-    # back-to-back launches.  persistent mode: so100_rollout_fused, one launch = T x N env-steps; otherwise so100_step_fused.
-    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-    if args.policy == "persistent":
-        kernel_name, units, reps = "so100_rollout_fused", n * T, 12
-        for _ in range(2):
-            sim.rollout(chunks[0], counter[0]); counter[0] += T
-        torch.cuda.synchronize(dev); e0.record()
-        for _ in range(reps):
-            sim.rollout(chunks[0], counter[0]); counter[0] += T
-        e1.record(); torch.cuda.synchronize(dev)
-    else:
-        kernel_name, units, reps = "so100_step_fused", n, 200
-        a2 = (torch.rand(n, 6, device=dev) * 2 - 1).contiguous()
-        for _ in range(20):
-            sim.step(a2)
-        torch.cuda.synchronize(dev); e0.record()
-        for _ in range(reps):
-            sim.step(a2)
-        e1.record(); torch.cuda.synchronize(dev)
-    kern_ms = e0.elapsed_time(e1) / reps
+    run(args.warmup)
+    first, first_own = timed(False)
+    # repeats of the timed region: as many as fit ~1.5 s (3..40) unless given; every rank must agree on the count
+    reps = args.repeats if args.repeats > 0 else max(3, min(40, int(1.5 / max(first, 1e-6))))
+    if use_dist:
+        rr = torch.tensor([reps], device=dev); dist.broadcast(rr, src=0); reps = int(rr.item())
+    dts, owns = [first], [first_own]
+    rec = args.policy == "persistent"                        # one event pair per 64-step launch costs nothing; per-step pairs would
+    for _ in range(reps - 1):
+        d, o = timed(rec)
+        dts.append(d); owns.append(o)
+    if len(kev) == 0:                                        # stepwise modes (or a single repeat): one more pass, only for the kernel events
+        timed(True)
+    torch.cuda.synchronize(dev)
+    order = sorted(range(len(dts)), key=lambda i: dts[i])
+    med = order[len(order) // 2]
+    dt = dts[med]
+    kern_total_ms = sum(a.elapsed_time(b) for a, b, _ in kev); kern_units = sum(u for _, _, u in kev)
+    units = kev[0][2]                                        # env-steps of one full launch (the first recorded one)
+    kern_ms = kern_total_ms / kern_units * units             # average duration of a launch of `units` env-steps
+    kernel_name = "so100_rollout_fused" if args.policy == "persistent" else ("so100_step_mw" if n <= 16384 else "so100_step_fused")
+    per_rank = None
+    if use_dist:                                             # every rank's own rate over the median repeat
+        mine = torch.tensor([n * args.steps / owns[med]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(allr, mine)
+        per_rank = [float(x.item()) for x in allr]
 
     # HBM traffic of the dominant kernel: rocprofv3 PMC counters cannot be collected from inside this process; the
-    # committed PMC pass (profiles/r01_c_pmc_summary.json, same workload / batch size) is quoted when it matches.
-    traffic = None
+    # committed PMC pass is quoted only when it was taken on THIS kernel source (fingerprint), workload and batch size.
+    traffic, traffic_note = None, "no committed PMC pass matches this kernel source / workload / batch size"
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_j_pmc_summary.json" if args.policy == "persistent" else "r01_c_pmc_summary.json")))
-        if args.workload == "env01_free" and n == 4096:
-            key = "rollout_fused" if args.policy == "persistent" else "step_fused"
-            traffic = [v for k, v in pmc["kernels"].items() if key in k][0]["hbm_traffic_bytes_per_launch"]
-    except Exception:
-        traffic = None
+        import glob
+        sha = source_sha16()
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json"))):
+            pmc = json.load(open(f))
+            if pmc.get("source_sha16") != sha or pmc.get("bench_workload") != args.workload or pmc.get("envs") != n or pmc.get("policy", "persistent") != args.policy:
+                continue
+            hit = [v for k, v in pmc["kernels"].items() if kernel_name in k and "hbm_traffic_bytes_per_launch" in v]
+            if hit:
+                traffic = hit[0]["hbm_traffic_bytes_per_launch"]; traffic_note = os.path.basename(f)
+    except Exception as ex:                                  # a broken summary file must not break the bench line
+        traffic, traffic_note = None, f"PMC summary unreadable: {ex}"
 
     if rank == 0:
+        bytes_per = BYTES_PER_ENV_STEP_BY_KIND.get((kind, bool(flags & CONTACT_BITS)), BYTES_PER_ENV_STEP)
         value = world * n * args.steps / dt
-        achieved = BYTES_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e9
+        achieved = bytes_per * units / (kern_ms * 1e-3) / 1e9
         out = {
             "metric": "env steps/sec at 4096 envs/GPU, Env01 PPO rollout", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: Env{kind:02d} x {n} envs/GPU, frame_skip 16, "
-                                   + ("contact disabled, no constraint solver (BASELINE.json configs[1])" if args.workload == "env01_free" else "friction-loss + limits + cube/floor contact")
+            "repeats": len(dts), "value_min": world * n * args.steps / max(dts), "value_max": world * n * args.steps / min(dts),
+            "ms_per_step_min": min(dts) / args.steps * 1e3, "ms_per_step_max": max(dts) / args.steps * 1e3,
+            "rccl_ranks": rccl_ranks, "per_rank_env_steps_per_s": per_rank,
+            "config": {"workload": f"{args.workload}: Env{kind:02d} x {n} envs/GPU, frame_skip 16, " + wl_desc
                                    + ", SB3-MlpPolicy-shaped rollout (" + args.policy + " policy), randomized resets, staggered episodes",
                        "envs_per_gpu": n, "rollout_chunk": T, "parallelism": f"env-sharded x{world}, RCCL gather per chunk" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)", "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * units, "kernel": kernel_name, "kernel_ms": kern_ms, "env_steps_per_launch": units,
-                         "bytes_per_env_step": BYTES_PER_ENV_STEP, "kernel_env_steps_per_s": units / (kern_ms * 1e-3),
-                         "valu": {"flop_per_env_step": FLOP_PER_ENV_STEP, "flop_per_env_step_survey_estimate": FLOP_PER_ENV_STEP_SURVEY,
-                                  "achieved_tflops": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12, "peak_tflops": VALU_PEAK_TFLOPS,
-                                  "frac": FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TFLOPS}},
+                         "traffic": traffic, "traffic_source": traffic_note, "traffic_unit": "bytes per launch (FETCH_SIZE+WRITE_SIZE, PMC pass in profiles/)",
+                         "algorithmic_bytes_per_launch": bytes_per * units, "kernel": kernel_name, "kernel_ms": kern_ms, "kernel_launches_timed": len(kev),
+                         "env_steps_per_launch": units, "bytes_per_env_step": bytes_per, "kernel_env_steps_per_s": units / (kern_ms * 1e-3)},
         }
+        if args.workload == "env01_free":                    # the measured instruction count (PMC) is for this workload only
+            tf = FLOP_PER_ENV_STEP * units / (kern_ms * 1e-3) / 1e12
+            out["roofline"]["valu"] = {"flop_per_env_step": FLOP_PER_ENV_STEP, "flop_per_env_step_survey_estimate": FLOP_PER_ENV_STEP_SURVEY,
+                                       "achieved_tflops": tf, "peak_tflops": VALU_PEAK_TFLOPS, "frac": tf / VALU_PEAK_TFLOPS}
+        if world == 1 and not args.no_sb3_path:
+            out["sb3_vecenv_path"] = sb3_vecenv_path(kind, flags, n, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(kind, flags, 2)
         if world == 1 and args.workload == "env01_free" and not args.no_large_batch:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SO100_ABI_VERSION 1
+#define SO100_ABI_VERSION 2
 
 /* env kinds == the reference's registered ids Env01-v1 .. Env06-v1 (ref: __init__.py:5-45) */
 #define SO100_ENV01 1   /* ref: envs/env01_v1.py  reach, random start pose              obs 15 */
@@ -85,7 +85,8 @@ typedef struct {
     int32_t*     ep_length_dev;    /* [N] Monitor's info["episode"]["l"], written where done; nullable */
     const float* inject_dev;       /* [N][SO100_NINJECT] uniforms replacing the device RNG (parity tests); nullable */
     float*       rollout_row_dev;  /* [N][obs_dim+10] row of a rollout buffer (layout: so100_policy_io); the step writes
-                                      reward -> column obs_dim+6 and done (0/1) -> column obs_dim+7; nullable */
+                                      reward -> column obs_dim+6 and done -> column obs_dim+7 (0 = running, 1 = terminated,
+                                      2 = TimeLimit-truncated only: what SB3's collect_rollouts bootstraps); nullable */
 } so100_step_io;
 
 /* ---- rollout-side helper (caller of the hot path) ------------------------------------------
@@ -110,7 +111,7 @@ typedef struct {
     float*       act_raw_dev;      /* [N][6] unclipped sample (what SB3 stores); nullable                   */
     float*       value_dev;        /* [N]; nullable                                                         */
     float*       logp_dev;         /* [N]; nullable                                                         */
-    float*       rollout_row_dev;  /* [N][obs_dim+10] = obs | raw action(6) | reward | done | value | logp; nullable */
+    float*       rollout_row_dev;  /* [N][obs_dim+10] = obs | raw action(6) | reward | done (0/1/2) | value | logp; nullable */
 } so100_policy_io;
 
 int  so100_policy_forward(so100_sim* sim, const so100_policy_weights* w, const so100_policy_io* io,
@@ -121,7 +122,7 @@ int  so100_policy_forward(so100_sim* sim, const so100_policy_weights* w, const s
  * calling so100_policy_forward(step_counter0 + t) + so100_step T times.  ref: the loop body of stable_baselines3
  * OnPolicyAlgorithm.collect_rollouts driven from main.py:234-238. */
 typedef struct {
-    float*   rollout_dev;          /* [T][N][obs_dim+10] rows: obs | raw action(6) | reward | done | value | logp   */
+    float*   rollout_dev;          /* [T][N][obs_dim+10] rows: obs | raw action(6) | reward | done (0/1/2) | value | logp */
     float*   obs_dev;              /* [N][obs_dim] in: current observation; out: observation after the last step     */
     float*   rew_dev;              /* [N] last step's reward                                                        */
     uint8_t* done_dev;             /* [N] last step's done                                                          */
@@ -129,6 +130,9 @@ typedef struct {
     float*   terminal_obs_dev;     /* [N][obs_dim] written where an episode ended (latest); nullable                 */
     float*   ep_return_dev;        /* [N] nullable                                                                  */
     int32_t* ep_length_dev;        /* [N] nullable                                                                  */
+    float*   terminal_obs_chunk_dev; /* [T][N][obs_dim] info["terminal_observation"] of EVERY episode end inside the chunk,
+                                      written where done != 0 (other entries untouched): what the learner needs to bootstrap
+                                      gamma * V(terminal_observation) on truncated steps; nullable                     */
 } so100_rollout_io;
 
 int  so100_rollout(so100_sim* sim, const so100_policy_weights* w, const so100_rollout_io* io, int32_t T,
@@ -151,7 +155,7 @@ void so100_destroy(so100_sim* sim);
 int  so100_reset(so100_sim* sim, const uint8_t* mask_dev, const float* inject_dev, float* obs_dev, void* hip_stream);
 
 /* One launch: the 4-wave latency kernel for N <= 16384, the one-wave-per-64-envs throughput kernel above (results agree
- * to the last bit or two; SO100_STEP_KERNEL=single in the environment at so100_create forces the latter). */
+ * to the last bit or two). */
 int  so100_step(so100_sim* sim, const so100_step_io* io, void* hip_stream);
 
 /* ref: reads / writes of data.qpos, data.qvel (MjData), SoA: qpos_dev [13][N], qvel_dev [12][N] */

@@ -6,19 +6,26 @@ buffer writes; ref: main.py:234-238 -> model.learn) with two kernel launches per
     batch = col.collect(64)                                       # dict of [T, N, ...] device tensors
     col.load_policy(sb3_policy.state_dict())                      # after each learner update
 
-`batch["last_values"]` / GAE are left to the learner (SB3's RolloutBuffer.compute_returns_and_advantage needs them).
+TimeLimit truncations are bootstrapped like SB3's collect_rollouts does (`rewards += gamma * V(terminal_observation)`,
+done code 2 in the rollout row; see rollout.bootstrap_truncated); `batch["last_values"]` / GAE are left to the learner
+(SB3's RolloutBuffer.compute_returns_and_advantage needs them).
 """
 import torch
 
 from .lib import POLICY_TENSORS, SB3_STATE_DICT_KEYS
-from .rollout import RolloutChunk, gather_rollout
+from .rollout import RolloutChunk, bootstrap_truncated, gather_rollout
 
 
 class RolloutCollector:
-    def __init__(self, vec_env, state_dict, T=64, persistent=None):
+    def __init__(self, vec_env, state_dict, T=64, persistent=None, gamma=0.99, bootstrap_truncated=True):
         self.env = vec_env; self.sim = vec_env.sim
         self.T = T
         self.chunk = RolloutChunk(T, self.sim.n, self.sim.obs_dim, self.sim.device)
+        # SB3 adds gamma * V(terminal_observation) to the reward of a step that ended by TimeLimit truncation alone
+        # (OnPolicyAlgorithm.collect_rollouts); every episode end of Env01/02/06 is such a truncation.  The kernels mark them
+        # (done column == 2) and deliver the terminal observations; the value net is applied here, before any gather.
+        self.gamma = gamma; self.bootstrap = bootstrap_truncated
+        self.tobs = torch.zeros(T, self.sim.n, self.sim.obs_dim, device=self.sim.device) if bootstrap_truncated else None
         self.act = torch.zeros(self.sim.n, 6, device=self.sim.device)
         self.counter = 0
         # one launch per chunk (so100_rollout: lowest latency, but one physics wave per CU => best up to 256 CUs x 64
@@ -52,6 +59,22 @@ class RolloutCollector:
         t = {k: state_dict[SB3_STATE_DICT_KEYS[k]].detach().to(self.sim.device, torch.float32).contiguous() for k in POLICY_TENSORS}
         self.sim.set_policy(t)
 
+    @torch.no_grad()
+    def _value(self, obs):
+        """V(obs) with the weights the kernels are using (SB3 value tower: 2 x 64 tanh + linear)."""
+        t = self.sim._policy_tensors
+        h = torch.tanh(torch.addmm(t["vf_b0"], obs, t["vf_w0"].t()))
+        h = torch.tanh(torch.addmm(t["vf_b1"], h, t["vf_w1"].t()))
+        return torch.addmm(t["v_b"], h, t["v_w"].t()).squeeze(-1)
+
+    def state_dict(self):
+        """What a resumed run needs beside the sim checkpoint: the policy-noise Philox counter (so that noise is not
+        reused from 0) and whether the first reset has happened."""
+        return {"counter": int(self.counter), "started": bool(self._started)}
+
+    def load_state_dict(self, sd):
+        self.counter = int(sd["counter"]); self._started = bool(sd["started"])
+
     def collect(self, T=None, gather_dst=None):
         """Run T vectorised steps; returns the unpacked chunk (views into a reused buffer).  With torch.distributed
         initialised and gather_dst set, the packed chunk is gathered to that rank (RCCL) and unpacked there."""
@@ -60,15 +83,18 @@ class RolloutCollector:
         if not self._started:
             self.env.reset_tensor(); self._started = True
         if self.persistent:
-            self.sim.rollout(self.chunk.buf[:T], self.counter)
+            self.sim.rollout(self.chunk.buf[:T], self.counter, terminal_obs_chunk=None if self.tobs is None else self.tobs[:T])
             self.counter += T
         else:
             for t in range(T):
                 row = self.chunk.buf[t]
                 self.sim.policy_forward(self.sim.obs, self.act, self.counter, rollout_row=row)
-                self.sim.step(self.act, rollout_row=row)
+                self.sim.step(self.act, rollout_row=row, terminal_obs=None if self.tobs is None else self.tobs[t])
                 self.counter += 1
         buf = self.chunk.buf[:T]
+        if self.bootstrap:
+            o = self.sim.obs_dim
+            bootstrap_truncated(buf[..., o + 6], buf[..., o + 7], self.tobs[:T], self._value, self.gamma)
         last_obs = self.sim.obs
         if gather_dst is not None:
             buf = gather_rollout(buf.contiguous(), dst=gather_dst)

@@ -23,6 +23,7 @@ struct RolloutArgs {
     int32_t T;
     uint32_t step_counter0;      // policy-noise Philox counter of the first step
     const float* obs_in;         // [N][OD] current observation (reset or previous launch)
+    float* tobs_chunk;           // [T][N][OD] terminal observation of every episode end inside the chunk (written where done); nullable
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -471,8 +472,12 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 for (int k = 0; k < OD; k++) { oxt[lane][k] = obs[k]; last_obs[k] = obs[k]; }
                 last = r;
                 if (live) {
-                    row[OD + 6] = r.reward; row[OD + 7] = r.done ? 1.0f : 0.0f;
+                    row[OD + 6] = r.reward; row[OD + 7] = r.done ? (r.trunc_only ? 2.0f : 1.0f) : 0.0f;
                     if (r.done) {
+                        if (ra.tobs_chunk) {
+#pragma unroll
+                            for (int k = 0; k < OD; k++) ra.tobs_chunk[((size_t)t*p.n + (size_t)env)*OD + k] = tobs[k];
+                        }
                         if (tobs_out) {
 #pragma unroll
                             for (int k = 0; k < OD; k++) tobs_out[(size_t)env*OD + k] = tobs[k];

@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
     io.rew[env] = r.reward;
     if (io.rollout_row) {
         io.rollout_row[(size_t)env*(OD + 10) + OD + 6] = r.reward;
-        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? 1.0f : 0.0f;
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? (r.trunc_only ? 2.0f : 1.0f) : 0.0f;
     }
     io.done[env] = r.done ? 1 : 0;
     io.trunc[env] = r.trunc_only ? 1 : 0;
@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     io.rew[env] = r.reward;
     if (io.rollout_row) {
         io.rollout_row[(size_t)env*(OD + 10) + OD + 6] = r.reward;
-        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? 1.0f : 0.0f;
+        io.rollout_row[(size_t)env*(OD + 10) + OD + 7] = r.done ? (r.trunc_only ? 2.0f : 1.0f) : 0.0f;
     }
     io.done[env] = r.done ? 1 : 0;
     io.trunc[env] = r.trunc_only ? 1 : 0;
@@ -205,7 +205,6 @@ struct so100_sim {
     SimParams prm;
     float* state = nullptr;        // [SF_COUNT][N]
     float* start_tab = nullptr;    // [36][6]
-    bool single_wave_step = false; // SO100_STEP_KERNEL=single in the environment at so100_create: always so100_step_fused (A/B knob for tools/)
 };
 
 namespace {
@@ -224,7 +223,7 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 constexpr int MW_MAX_ENVS = 16384;   // up to here the 4-wave step kernel wins (256 CUs x 64 envs); beyond, the chip is full anyway
 
 template <int KIND> int launch_step(so100_sim* s, const StepPtrs& io, hipStream_t st) {
-    const bool mw = s->prm.n <= MW_MAX_ENVS && !s->single_wave_step;
+    const bool mw = s->prm.n <= MW_MAX_ENVS;
     const dim3 g = grid_for(s->prm.n), b(mw ? 256 : WG);
 #define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, s->prm, io); \
                              else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, s->prm, io); } while (0)
@@ -304,7 +303,6 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         (void)hipFree(s->state); if (s->start_tab) (void)hipFree(s->start_tab); delete s;
         return fail(SO100_E_NOMEM, "so100_create: start table upload failed%s");
     }
-    { const char* kv = getenv("SO100_STEP_KERNEL"); s->single_wave_step = kv && strcmp(kv, "single") == 0; }
     const int rc = DISPATCH_KIND(cfg->env_kind, launch_init)(s);
     if (rc != 0) { (void)hipFree(s->state); (void)hipFree(s->start_tab); delete s; return rc; }
     *out = s;
@@ -350,23 +348,13 @@ int so100_policy_forward(so100_sim* s, const so100_policy_weights* w, const so10
     memcpy(&pw, w, sizeof pw);
     PolicyIO pio; pio.obs = io->obs_dev; pio.noise = io->noise_dev; pio.act_env = io->act_env_dev; pio.act_raw = io->act_raw_dev;
     pio.value = io->value_dev; pio.logp = io->logp_dev; pio.rollout_row = io->rollout_row_dev;
-    // default: the matrix-core kernel, grid-stride over tiles of 64 envs, two workgroups per CU resident;
-    // SO100_POLICY_KERNEL=valu in the environment selects the older VALU kernel (A/B knob for tools/kbench_policy.py)
-    static const bool valu = []{ const char* e = getenv("SO100_POLICY_KERNEL"); return e && strcmp(e, "valu") == 0; }();
+    // the matrix-core kernel, grid-stride over tiles of 64 envs, two workgroups per CU resident
     const int ntiles = (s->prm.n + 63)/64;
-    if (!valu) {
-        const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));
-        if (so100_obs_dim(s->cfg.env_kind) == 15)
-            hipLaunchKernelGGL((so100_policy_forward_mfma<15>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
-        else
-            hipLaunchKernelGGL((so100_policy_forward_mfma<8>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
-    } else {
-        const dim3 grid((unsigned)ntiles);
-        if (so100_obs_dim(s->cfg.env_kind) == 15)
-            hipLaunchKernelGGL((so100_policy_forward_kernel<15, 8>), grid, dim3(512), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
-        else
-            hipLaunchKernelGGL((so100_policy_forward_kernel<8, 8>), grid, dim3(512), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
-    }
+    const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512));
+    if (so100_obs_dim(s->cfg.env_kind) == 15)
+        hipLaunchKernelGGL((so100_policy_forward_mfma<15>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
+    else
+        hipLaunchKernelGGL((so100_policy_forward_mfma<8>), grid, dim3(256), 0, (hipStream_t)stream, s->prm.n, pw, pio, s->prm.seed_lo, s->prm.seed_hi, s->prm.env_id_offset, step_counter);
     HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     return 0;
 }
@@ -381,7 +369,7 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
     DeviceGuard g(s->cfg.device);
     if (!g.ok) return fail(SO100_E_NODEVICE, "so100_rollout: cannot select the device%s");
     PolicyWeights pw; memcpy(&pw, w, sizeof pw);
-    RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev;
+    RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev; ra.tobs_chunk = io->terminal_obs_chunk_dev;
     const dim3 grid((unsigned)((s->prm.n + 63)/64));
     hipStream_t st = (hipStream_t)stream;
 #define SO100_RL(KIND, FLV, NW) hipLaunchKernelGGL((so100_rollout_fused<KIND, FLV, NW>), grid, dim3(64*NW), 0, st, s->prm, s->state, s->start_tab, \
@@ -401,6 +389,7 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
 int so100_get_state(so100_sim* s, float* qpos_dev, float* qvel_dev, void* stream) {
     if (!s || !qpos_dev || !qvel_dev) return fail(SO100_E_INVALID, "so100_get_state: null argument%s");
     DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_get_state: cannot select the device%s");
     const size_t n = (size_t)s->prm.n;
     HIP_TRY(hipMemcpyAsync(qpos_dev, s->state + (size_t)SF_QPOS0*n, 13*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
     HIP_TRY(hipMemcpyAsync(qvel_dev, s->state + (size_t)SF_QVEL0*n, 12*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
@@ -409,6 +398,7 @@ int so100_get_state(so100_sim* s, float* qpos_dev, float* qvel_dev, void* stream
 int so100_set_state(so100_sim* s, const float* qpos_dev, const float* qvel_dev, void* stream) {
     if (!s || !qpos_dev || !qvel_dev) return fail(SO100_E_INVALID, "so100_set_state: null argument%s");
     DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_set_state: cannot select the device%s");
     const size_t n = (size_t)s->prm.n;
     HIP_TRY(hipMemcpyAsync(s->state + (size_t)SF_QPOS0*n, qpos_dev, 13*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
     HIP_TRY(hipMemcpyAsync(s->state + (size_t)SF_QVEL0*n, qvel_dev, 12*n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
@@ -418,6 +408,7 @@ int so100_set_state(so100_sim* s, const float* qpos_dev, const float* qvel_dev, 
 int so100_get_field(so100_sim* s, int32_t field, void* out_dev, void* stream) {
     if (!s || !out_dev || field < 0 || field >= SF_COUNT) return fail(SO100_E_INVALID, "so100_get_field: bad argument%s");
     DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_get_field: cannot select the device%s");
     const size_t n = (size_t)s->prm.n;
     HIP_TRY(hipMemcpyAsync(out_dev, s->state + (size_t)field*n, n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
     return 0;
@@ -425,6 +416,7 @@ int so100_get_field(so100_sim* s, int32_t field, void* out_dev, void* stream) {
 int so100_set_field(so100_sim* s, int32_t field, const void* in_dev, void* stream) {
     if (!s || !in_dev || field < 0 || field >= SF_COUNT) return fail(SO100_E_INVALID, "so100_set_field: bad argument%s");
     DeviceGuard g(s->cfg.device);
+    if (!g.ok) return fail(SO100_E_NODEVICE, "so100_set_field: cannot select the device%s");
     const size_t n = (size_t)s->prm.n;
     HIP_TRY(hipMemcpyAsync(s->state + (size_t)field*n, in_dev, n*sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream), SO100_E_LAUNCH);
     return 0;

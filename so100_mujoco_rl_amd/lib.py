@@ -19,6 +19,7 @@ F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR
 B_BAD_STATE = 128            # bit of the `bits` state row latched when a non-finite state ended an episode (csrc/so100_task.hpp)
 NINJECT = 16
+ABI_VERSION = 2              # include/so100_sim.h: SO100_ABI_VERSION
 
 
 class So100Error(RuntimeError):
@@ -54,7 +55,7 @@ class PolicyWeights(C.Structure):
 
 class RolloutIO(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("rollout_dev", "obs_dev", "rew_dev", "done_dev", "trunc_dev", "terminal_obs_dev",
-                                          "ep_return_dev", "ep_length_dev")]
+                                          "ep_return_dev", "ep_length_dev", "terminal_obs_chunk_dev")]
 
 
 class PolicyIO(C.Structure):
@@ -101,7 +102,7 @@ def load():
         L.so100_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.so100_get_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.so100_set_field.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
-        if L.so100_abi_version() != 1:
+        if L.so100_abi_version() != ABI_VERSION:
             raise So100Error("libso100sim.so ABI version mismatch")
         _lib = L
     return _lib
@@ -168,15 +169,16 @@ class So100Sim:
         _check(self.L.so100_reset(self.h, m, i, self.obs.data_ptr(), self._stream()), "so100_reset")
         return self.obs
 
-    def step(self, actions, inject=None, rollout_row=None):
+    def step(self, actions, inject=None, rollout_row=None, terminal_obs=None):
         """actions: float32 [N,6] on the device.  Returns views of the handle's output tensors.
-        rollout_row: optional float32 [N, obs_dim+10] row of a rollout buffer; reward/done are written into it."""
+        rollout_row: optional float32 [N, obs_dim+10] row of a rollout buffer; reward/done are written into it.
+        terminal_obs: optional float32 [N, obs_dim] destination of the terminal observations (default: self.terminal_obs)."""
         io = self._io
         io.rollout_row_dev = _ptr(rollout_row, torch.float32, (self.n, self.obs_dim + 10), self.device)
         io.act_dev = _ptr(actions, torch.float32, (self.n, 6), self.device)
         io.obs_dev = self.obs.data_ptr(); io.rew_dev = self.rew.data_ptr()
         io.done_dev = self.done.data_ptr(); io.trunc_dev = self.trunc.data_ptr()
-        io.terminal_obs_dev = self.terminal_obs.data_ptr()
+        io.terminal_obs_dev = self.terminal_obs.data_ptr() if terminal_obs is None else _ptr(terminal_obs, torch.float32, (self.n, self.obs_dim), self.device)
         io.ep_return_dev = self.ep_return.data_ptr(); io.ep_length_dev = self.ep_length.data_ptr()
         io.inject_dev = _ptr(inject, torch.float32, (self.n, NINJECT), self.device)
         _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
@@ -203,12 +205,14 @@ class So100Sim:
         io.rollout_row_dev = _ptr(rollout_row, torch.float32, (self.n, self.obs_dim + 10), self.device)
         _check(self.L.so100_policy_forward(self.h, C.byref(self._pw), C.byref(io), int(step_counter) & 0xFFFFFFFF, self._stream()), "so100_policy_forward")
 
-    def rollout(self, rollout_buf, step_counter0):
+    def rollout(self, rollout_buf, step_counter0, terminal_obs_chunk=None):
         """T = rollout_buf.shape[0] steps of {policy, sample, env step, buffer write} in one launch (persistent kernel).
-        rollout_buf: float32 [T, N, obs_dim+10].  Uses / updates the handle's obs, rew, done, ... tensors."""
+        rollout_buf: float32 [T, N, obs_dim+10].  Uses / updates the handle's obs, rew, done, ... tensors.
+        terminal_obs_chunk: optional float32 [T, N, obs_dim], receives the terminal observation wherever an episode ended."""
         T = rollout_buf.shape[0]
         io = RolloutIO(_ptr(rollout_buf, torch.float32, (T, self.n, self.obs_dim + 10), self.device), self.obs.data_ptr(), self.rew.data_ptr(),
-                       self.done.data_ptr(), self.trunc.data_ptr(), self.terminal_obs.data_ptr(), self.ep_return.data_ptr(), self.ep_length.data_ptr())
+                       self.done.data_ptr(), self.trunc.data_ptr(), self.terminal_obs.data_ptr(), self.ep_return.data_ptr(), self.ep_length.data_ptr(),
+                       _ptr(terminal_obs_chunk, torch.float32, (T, self.n, self.obs_dim), self.device))
         _check(self.L.so100_rollout(self.h, C.byref(self._pw), C.byref(io), T, int(step_counter0) & 0xFFFFFFFF, self._stream()), "so100_rollout")
 
     def get_state(self):
@@ -241,11 +245,18 @@ class So100Sim:
                  config=np.array([c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip,
                                   c.max_episode_steps, c.seed, c.env_id_offset], dtype=np.int64))
 
-    def load_state(self, path):
+    def load_state(self, path, allow_config_mismatch=False):
         with np.load(path, allow_pickle=False) as z:
             words, names, obs, conf = z["words"], [str(n) for n in z["names"]], z["obs"], z["config"]
         if int(conf[0]) != self.cfg.env_kind or int(conf[1]) != self.n:
             raise So100Error(f"checkpoint is for env kind {int(conf[0])} x {int(conf[1])} envs, this sim is kind {self.cfg.env_kind} x {self.n}")
+        # resume is bit exact only under the configuration the checkpoint was taken with: refuse anything else
+        c = self.cfg
+        mine = [c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip, c.max_episode_steps, c.seed, c.env_id_offset]
+        labels = ["env_kind", "num_envs", "flags", "solver_iters", "contact_iters", "frame_skip", "max_episode_steps", "seed", "env_id_offset"]
+        diff = [f"{l}: checkpoint {int(a)} != sim {int(b)}" for l, a, b in zip(labels, conf, mine) if int(a) != int(b)]
+        if diff and not allow_config_mismatch:
+            raise So100Error("checkpoint was taken under a different configuration (" + "; ".join(diff) + "); pass allow_config_mismatch=True to load it anyway")
         missing = set(self.field_names()) - set(names)
         if missing:
             raise So100Error(f"checkpoint lacks state fields {sorted(missing)}")

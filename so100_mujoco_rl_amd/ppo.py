@@ -1,7 +1,10 @@
 """Plain-PyTorch PPO on top of the on-device rollout collector -- the learner used by `main.py train` when
-stable-baselines3 is not importable (it is not in this image).  Hyper-parameters are SB3's PPO defaults
+stable-baselines3 is not importable (it is not in this image).  Network and loss follow SB3's PPO
 (ref: main.py:56-64 -> stable_baselines3.PPO("MlpPolicy")): 2x64 tanh towers, gamma 0.99, gae_lambda 0.95, clip 0.2,
-lr 3e-4, vf_coef 0.5, max_grad_norm 0.5; epochs 4 instead of 10 (the batch is 262 144 samples per update).  On a GPU the
+lr 3e-4, vf_coef 0.5, max_grad_norm 0.5.  NOT SB3's defaults: 4 epochs instead of 10, minibatches of 32 768 instead of
+64, rollouts of 64 steps x N envs instead of 2048 x 1 (the batch is 262 144 samples per update at 4096 envs).
+TimeLimit truncations are bootstrapped by the collector exactly as SB3 does (rewards += gamma V(terminal_obs)), so
+`dones` below ends the GAE recursion with the right target for both terminations and truncations.  On a GPU the
 update is replayed from two captured hipGraphs (GAE pass, minibatch step): it is launch-bound otherwise.
 The network's state_dict keys equal SB3's ActorCriticPolicy keys, so checkpoints and RolloutCollector.load_policy()
 interoperate with an SB3 policy."""

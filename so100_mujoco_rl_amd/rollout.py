@@ -22,7 +22,8 @@ def pack_width(obs_dim, act_dim=6):
 
 
 class RolloutChunk:
-    """[T, N, k] on-device buffer: obs | action | reward | done | value | logp."""
+    """[T, N, k] on-device buffer: obs | action | reward | done | value | logp.  The done column is 0 (running),
+    1 (terminated) or 2 (TimeLimit-truncated only), as the kernels write it (include/so100_sim.h)."""
 
     def __init__(self, T, n, obs_dim, device, act_dim=6):
         self.T, self.n, self.obs_dim, self.act_dim = T, n, obs_dim, act_dim
@@ -37,8 +38,20 @@ class RolloutChunk:
     def unpack(self, buf=None):
         b = self.buf if buf is None else buf
         o, a = self.obs_dim, self.act_dim
-        return {"obs": b[..., :o], "actions": b[..., o:o + a], "rewards": b[..., o + a], "dones": b[..., o + a + 1],
-                "values": b[..., o + a + 2], "log_probs": b[..., o + a + 3]}
+        code = b[..., o + a + 1]
+        return {"obs": b[..., :o], "actions": b[..., o:o + a], "rewards": b[..., o + a], "dones": (code != 0).to(b.dtype),
+                "truncated": code == 2, "values": b[..., o + a + 2], "log_probs": b[..., o + a + 3]}
+
+
+def bootstrap_truncated(rewards, done_code, terminal_obs, value_fn, gamma):
+    """SB3's TimeLimit handling in OnPolicyAlgorithm.collect_rollouts: where an episode was only truncated
+    (`infos["TimeLimit.truncated"]`, done code 2) the learner must not treat the step as terminal, so
+    `rewards += gamma * V(terminal_observation)` there, in place.  Dense and sync-free: V is evaluated on the whole
+    [T, N, obs_dim] terminal-observation chunk (entries that are not episode ends hold stale values and are masked)."""
+    mask = done_code == 2
+    v = value_fn(terminal_obs.reshape(-1, terminal_obs.shape[-1])).reshape(rewards.shape)
+    rewards.add_(torch.where(mask, gamma * v, torch.zeros_like(v)))
+    return mask
 
 
 def gather_rollout(chunk_buf, dst=0, group=None):

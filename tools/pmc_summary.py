@@ -2,6 +2,9 @@
 kernels): python tools/pmc_summary.py gpurun_out/<tag> > profiles/<tag>_pmc_summary.json"""
 import collections, csv, glob, json, os, sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_sha16          # fingerprint of csrc/: bench.py quotes this pass only while it describes the current kernels
+
 root = sys.argv[1]
 T, N = 64, 4096
 
@@ -31,7 +34,9 @@ for sub in ("sq", "fetch", "write"):
 out = {"note": "rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over `python bench.py --steps 256 --warmup 64 "
                "--no-cpu-baseline` on one MI355X; per-dispatch averages. FETCH_SIZE / WRITE_SIZE in KB; no gfx950 x2 correction applied "
                "(dword-per-lane accesses, an uncalibrated width); the x2 value is given alongside.",
-       "workload": (sys.argv[2] if len(sys.argv) > 2 else "env01_free") + f", {N} envs, T = {T} steps per launch", "kernels": {}}
+       "workload": (sys.argv[2] if len(sys.argv) > 2 else "env01_free") + f", {N} envs, T = {T} steps per launch",
+       "bench_workload": (sys.argv[2] if len(sys.argv) > 2 else "env01_free"), "envs": N, "policy": "persistent", "source_sha16": source_sha16(),
+       "kernels": {}}
 for k, c in acc.items():
     d = {name: sum(v) / len(v) for name, v in c.items()}
     d["dispatches"] = {name: len(v) for name, v in c.items()}

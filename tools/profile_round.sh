@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect the round's rocprofv3 evidence on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag> [bench.py arguments, e.g. --workload env01_reference]   -> gpurun_out/<tag>/{stats,sq,fetch,write}/...
+#   tools/profile_round.sh <tag> [workload, e.g. env01_reference]   -> gpurun_out/<tag>/{stats,sq,fetch,write}/...
 # Passes are separate (kernel-trace --stats; then one --pmc group each), as the MI355X guide prescribes.
 set -e
 TAG=${1:-round}
 shift || true
-EXTRA="$*"
+WL=${1:-env01_free}
+EXTRA="--workload $WL --no-sb3-path"
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -17,5 +18,5 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- $PMCB > "$OUT/fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- $PMCB > "$OUT/write.log" 2>&1
 cd - > /dev/null
-python3 tools/pmc_summary.py "$OUT" "${EXTRA:-env01_free}" > "$OUT/pmc_summary.json"
+python3 tools/pmc_summary.py "$OUT" "$WL" > "$OUT/pmc_summary.json"
 tail -1 "$OUT/stats.log"
