@@ -144,6 +144,20 @@ void so100o_model_init(so100o_model* m) {
     m->timestep = SO100_TIMESTEP;
     m->gravity[2] = SO100_GRAVITY_Z;
     m->qpos0[9] = 1.0;                               /* cube quat identity */
+    for (int g = 0; g < SO100_NPAD; g++) {
+        m->pad_body[g] = SO100_PAD_LINK[g] + 2;
+        memcpy(m->pad_pos[g], SO100_PAD_POS[g], sizeof(double)*3);
+        memcpy(m->pad_size[g], SO100_PAD_SIZE[g], sizeof(double)*3);
+    }
+    m->pad_solref[0] = SO100_PAD_SOLREF_TIMECONST; m->pad_solref[1] = SO100_PAD_SOLREF_DAMPRATIO;
+    m->pad_solimp[0] = SO100_PAD_SOLIMP_D0; m->pad_solimp[1] = SO100_PAD_SOLIMP_DMAX; m->pad_solimp[2] = SO100_PAD_SOLIMP_WIDTH;
+    m->pad_solimp[3] = SO100_SOLIMP_MID; m->pad_solimp[4] = SO100_SOLIMP_POWER;
+    m->pad_friction = SO100_PAD_FRICTION;
+    m->def_solref[0] = SO100_SOLREF_TIMECONST; m->def_solref[1] = SO100_SOLREF_DAMPRATIO;
+    m->def_solimp[0] = SO100_SOLIMP_D0; m->def_solimp[1] = SO100_SOLIMP_DMAX; m->def_solimp[2] = SO100_SOLIMP_WIDTH;
+    m->def_solimp[3] = SO100_SOLIMP_MID; m->def_solimp[4] = SO100_SOLIMP_POWER;
+    m->def_friction = SO100_GEOM_FRICTION;
+    m->max_contacts = 16;                            /* the product's contact budget per env (csrc/so100_contact.hpp) */
 
     /* mj_setConst: dof_M0, dof_invweight0, body_invweight0 at qpos0, then kv from dampratio */
     so100o_data* d = (so100o_data*)calloc(1, sizeof *d);
@@ -166,6 +180,20 @@ void so100o_model_init(so100o_model* m) {
         for (int i = 6; i < 9; i++)  m->dof_invweight0[i] = tr;
         for (int i = 9; i < 12; i++) m->dof_invweight0[i] = ro;
         m->body_invweight0[CUBE][0] = tr; m->body_invweight0[CUBE][1] = ro;
+    }
+    /* body_invweight0 of the arm links (mj_setConst): A = J M^-1 J^T with J = mj_jacBodyCom at qpos0 (6 x nv: linear rows
+     * then angular rows); translational / rotational weight = mean of the respective diagonal block */
+    for (int b = 2; b < CUBE; b++) {
+        double Jb[6][NV], MiJ[6][NV];
+        memset(Jb, 0, sizeof Jb);
+        for (int j = 0; j <= b - 2; j++) {
+            double w[3]; cross3(w, d->cdof[j], d->xipos[b]);           /* omega x p + v_origin */
+            for (int a = 0; a < 3; a++) { Jb[a][j] = w[a] + d->cdof[j][3 + a]; Jb[3 + a][j] = d->cdof[j][a]; }
+        }
+        for (int r = 0; r < 6; r++) chol_solve(d->L, NV, Jb[r], MiJ[r]);
+        double tr = 0, ro = 0;
+        for (int r = 0; r < 3; r++) for (int i = 0; i < NV; i++) { tr += Jb[r][i]*MiJ[r][i]; ro += Jb[3 + r][i]*MiJ[3 + r][i]; }
+        m->body_invweight0[b][0] = tr / 3.0; m->body_invweight0[b][1] = ro / 3.0;
     }
     /* position actuator damping from dampratio (mj_setConst): kv = dampratio*2*sqrt(kp*M0) */
     for (int i = 0; i < 6; i++) m->kv[i] = SO100_ACT_DAMPRATIO * 2.0 * sqrt(m->kp * m->dof_M0[i]);
@@ -390,21 +418,40 @@ static void chol_solve(const double* L, int n, const double* b, double* x) {
 /* ================================================================================================
  * constraint rows (mj_makeConstraint + mj_makeImpedance) and the PGS solve (mj_solPGS)
  * ============================================================================================== */
-static double impedance(double pos_minus_margin) {          /* getimpedance(), default solimp */
-    const double d0 = SO100_SOLIMP_D0, dm = SO100_SOLIMP_DMAX, w = SO100_SOLIMP_WIDTH;
-    const double mid = SO100_SOLIMP_MID, p = SO100_SOLIMP_POWER;
+static double impedance_of(const double solimp[5], double pos_minus_margin) {      /* getimpedance() */
+    const double d0 = solimp[0], dm = solimp[1], w = solimp[2], mid = solimp[3], p = solimp[4];
+    if (d0 == dm || w <= SO100_MJMINVAL) return 0.5*(d0 + dm);
     double x = fabs(pos_minus_margin / w), y;
     if (x >= 1) return dm;
     if (x <= 0) return d0;
-    if (x <= mid) y = pow(x, p) / pow(mid, p - 1);
-    else          y = 1 - pow(1 - x, p) / pow(1 - mid, p - 1);
+    if (p == 1) y = x;
+    else if (x <= mid) y = pow(x, p) / pow(mid, p - 1);
+    else               y = 1 - pow(1 - x, p) / pow(1 - mid, p - 1);
     return d0 + y * (dm - d0);
 }
-static void solref_KB(double h, double* K, double* B) {
-    double tc = SO100_SOLREF_TIMECONST, dr = SO100_SOLREF_DAMPRATIO, dmax = SO100_SOLIMP_DMAX;
+static void solref_KB_of(const double solref[2], double dmax, double h, double* K, double* B) {
+    double tc = solref[0], dr = solref[1];
     if (tc < 2*h) tc = 2*h;                                  /* refsafe */
     *K = 1.0 / fmax(SO100_MJMINVAL, dmax*dmax*tc*tc*dr*dr);
     *B = 2.0 / fmax(SO100_MJMINVAL, dmax*tc);
+}
+static const double DEF_SOLIMP[5] = { SO100_SOLIMP_D0, SO100_SOLIMP_DMAX, SO100_SOLIMP_WIDTH, SO100_SOLIMP_MID, SO100_SOLIMP_POWER };
+static const double DEF_SOLREF[2] = { SO100_SOLREF_TIMECONST, SO100_SOLREF_DAMPRATIO };
+static double impedance(double pos_minus_margin) { return impedance_of(DEF_SOLIMP, pos_minus_margin); }   /* default solimp */
+static void solref_KB(double h, double* K, double* B) { solref_KB_of(DEF_SOLREF, SO100_SOLIMP_DMAX, h, K, B); }
+/* mj_contactParam (equal priority, solmix 1 : 1) followed by mj_assignRef / mj_assignImp (the clamp comes AFTER the mix) */
+static void mix_contact_params(const double ref1[2], const double imp1[5], double fr1, const double ref2[2], const double imp2[5], double fr2,
+                               double solref[2], double solimp[5], double* mu) {
+    const double mix = 0.5;
+    if (ref1[0] > 0 && ref2[0] > 0) for (int i = 0; i < 2; i++) solref[i] = mix*ref1[i] + (1 - mix)*ref2[i];
+    else for (int i = 0; i < 2; i++) solref[i] = fmin(ref1[i], ref2[i]);
+    for (int i = 0; i < 5; i++) solimp[i] = mix*imp1[i] + (1 - mix)*imp2[i];
+    solimp[0] = fmin(SO100_MJMAXIMP, fmax(SO100_MJMINIMP, solimp[0]));
+    solimp[1] = fmin(SO100_MJMAXIMP, fmax(SO100_MJMINIMP, solimp[1]));
+    solimp[2] = fmax(0.0, solimp[2]);
+    solimp[3] = fmin(SO100_MJMAXIMP, fmax(SO100_MJMINIMP, solimp[3]));
+    solimp[4] = fmax(1.0, solimp[4]);
+    *mu = fmax(fr1, fr2);
 }
 static int add_row(so100o_data* d, int type, int id, const double* J, double pos, double floss,
                    double diagApprox, double K, double B) {
@@ -419,10 +466,214 @@ static int add_row(so100o_data* d, int type, int id, const double* J, double pos
     return r;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * narrowphase.  Boxes are (centre c, rotation R row-major with the box axes as COLUMNS, half sizes h).
+ * ---------------------------------------------------------------------------------------------- */
+/* mjc_PlaneBox against the floor z = 0 (normal +z): every corner that is at / below the plane AND below the box centre, in
+ * corner order, at most 4; contact point midway between the corner and the plane */
+int so100o_plane_box(const double c[3], const double R[9], const double h[3], double pos[4][3], double dist[4]) {
+    int cnt = 0;
+    const double cdist = c[2];
+    for (int k = 0; k < 8 && cnt < 4; k++) {
+        const double v[3] = { (k & 1) ? h[0] : -h[0], (k & 2) ? h[1] : -h[1], (k & 4) ? h[2] : -h[2] };
+        double corner[3]; mat_vec3(corner, R, v);
+        const double ldist = corner[2];
+        if (cdist + ldist > 0 || ldist > 0) continue;
+        dist[cnt] = cdist + ldist;
+        pos[cnt][0] = corner[0] + c[0]; pos[cnt][1] = corner[1] + c[1]; pos[cnt][2] = corner[2] + c[2] - dist[cnt]*0.5;
+        cnt++;
+    }
+    return cnt;
+}
+
+/* Box-box, in the manner of mjc_BoxBox: separating-axis test over the 15 candidate axes, then
+ *   face axis  -> the incident face of the other box is clipped against the side planes of the reference face; contacts are
+ *                 the clipped polygon's vertices that lie at / below the reference face (at most 8), each midway between
+ *                 the two surfaces along the normal;
+ *   edge axis  -> one contact at the midpoint of the closest points of the two edges.
+ * The clipped polygon is enumerated in a fixed slot order (no dynamic vertex lists, so that the fp32 device code can follow
+ * the same order): per incident edge k = 0..3 its Liang-Barsky entry point (or start vertex) and, if it leaves the rectangle
+ * before its end vertex, its exit point; then the reference rectangle's corners that lie inside the incident face.
+ * An edge axis must beat the best face axis by 5 % (+ 1e-9) to be chosen: face contacts are the stabler manifold.
+ * The normal points from A to B.  MuJoCo's own function is not available to compare against: "parity unpinned". */
+int so100o_box_box(const double cA[3], const double RA[9], const double hA[3], const double cB[3], const double RB[9],
+                   const double hB[3], double pos[8][3], double normal[3], double dist[8]) {
+    double a[3][3], b[3][3], dd[3];                         /* box axes in the world */
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { a[i][k] = RA[3*k + i]; b[i][k] = RB[3*k + i]; }
+    for (int k = 0; k < 3; k++) dd[k] = cB[k] - cA[k];
+    double Rm[3][3], Ra[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Rm[i][j] = dot3(a[i], b[j]); Ra[i][j] = fabs(Rm[i][j]); }
+    double best = -1e300, bn[3] = {0, 0, 0}; int code = -1;
+    /* face axes of A (code 0-2) and of B (3-5) */
+    for (int i = 0; i < 3; i++) {
+        const double proj = dot3(dd, a[i]);
+        const double sep = fabs(proj) - (hA[i] + hB[0]*Ra[i][0] + hB[1]*Ra[i][1] + hB[2]*Ra[i][2]);
+        if (sep > 0) return 0;
+        if (sep > best) { best = sep; code = i; const double sg = proj < 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) bn[k] = sg*a[i][k]; }
+    }
+    for (int j = 0; j < 3; j++) {
+        const double proj = dot3(dd, b[j]);
+        const double sep = fabs(proj) - (hB[j] + hA[0]*Ra[0][j] + hA[1]*Ra[1][j] + hA[2]*Ra[2][j]);
+        if (sep > 0) return 0;
+        if (sep > best) { best = sep; code = 3 + j; const double sg = proj < 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) bn[k] = sg*b[j][k]; }
+    }
+    /* edge axes a_i x b_j (code 6 + 3 i + j) */
+    double ebest = -1e300, en[3] = {0, 0, 0}; int ecode = -1;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double L[3]; cross3(L, a[i], b[j]);
+        const double len = sqrt(dot3(L, L));
+        if (len < 1e-6) continue;                           /* parallel edges: the face axes cover it */
+        for (int k = 0; k < 3; k++) L[k] /= len;
+        const double proj = dot3(dd, L);
+        double ra = 0, rb = 0;
+        for (int k = 0; k < 3; k++) { ra += hA[k]*fabs(dot3(a[k], L)); rb += hB[k]*fabs(dot3(b[k], L)); }
+        const double sep = fabs(proj) - (ra + rb);
+        if (sep > 0) return 0;
+        if (sep > ebest) { ebest = sep; ecode = 6 + 3*i + j; const double sg = proj < 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) en[k] = sg*L[k]; }
+    }
+    if (ecode >= 0 && ebest*1.05 > best + 1e-9) { best = ebest; code = ecode; memcpy(bn, en, sizeof bn); }
+    memcpy(normal, bn, sizeof bn);
+
+    if (code >= 6) {
+        /* edge-edge: the supporting edge of A in direction +n and of B in direction -n; closest points of the two lines */
+        const int i = (code - 6) / 3, j = (code - 6) % 3;
+        double pa[3], pb[3];
+        for (int k = 0; k < 3; k++) { pa[k] = cA[k]; pb[k] = cB[k]; }
+        for (int q = 0; q < 3; q++) {
+            if (q != i) { const double sg = dot3(bn, a[q]) > 0 ? 1.0 : -1.0; for (int k = 0; k < 3; k++) pa[k] += sg*hA[q]*a[q][k]; }
+            if (q != j) { const double sg = dot3(bn, b[q]) > 0 ? -1.0 : 1.0; for (int k = 0; k < 3; k++) pb[k] += sg*hB[q]*b[q][k]; }
+        }
+        /* lines pa + s a_i, pb + t b_j */
+        double w0[3]; for (int k = 0; k < 3; k++) w0[k] = pb[k] - pa[k];
+        const double uu = Rm[i][j], d1 = dot3(a[i], w0), d2 = dot3(b[j], w0), den = 1.0 - uu*uu;
+        double sa = 0, tb = 0;
+        if (den > 1e-12) { sa = (d1 - uu*d2)/den; tb = (uu*d1 - d2)/den; }
+        sa = sa < -hA[i] ? -hA[i] : (sa > hA[i] ? hA[i] : sa);
+        tb = tb < -hB[j] ? -hB[j] : (tb > hB[j] ? hB[j] : tb);
+        for (int k = 0; k < 3; k++) pos[0][k] = 0.5*((pa[k] + sa*a[i][k]) + (pb[k] + tb*b[j][k]));
+        dist[0] = best;
+        return 1;
+    }
+
+    /* face contact: X = reference box (owner of the axis), Y = incident box */
+    const int refA = code < 3, r = refA ? code : code - 3;
+    const double (*x)[3] = refA ? a : b; const double (*y)[3] = refA ? b : a;
+    const double* cX = refA ? cA : cB; const double* cY = refA ? cB : cA;
+    const double* hX = refA ? hA : hB; const double* hY = refA ? hB : hA;
+    double nref[3]; for (int k = 0; k < 3; k++) nref[k] = refA ? bn[k] : -bn[k];          /* outward normal of the reference face */
+    int mi = 0; double mv = -1;
+    for (int k = 0; k < 3; k++) { const double v = fabs(dot3(nref, y[k])); if (v > mv) { mv = v; mi = k; } }
+    const double fs = dot3(nref, y[mi]) > 0 ? -1.0 : 1.0;   /* incident face: the one whose outward normal opposes nref most */
+    const int p1 = (mi + 1) % 3, p2 = (mi + 2) % 3, u1 = (r + 1) % 3, u2 = (r + 2) % 3;
+    double fc[3], rc[3];
+    for (int k = 0; k < 3; k++) { fc[k] = cY[k] + fs*hY[mi]*y[mi][k] - (cX[k] + hX[r]*nref[k]); rc[k] = cX[k] + hX[r]*nref[k]; }
+    /* incident face in reference-face coordinates (u, v in the rectangle's plane, w = signed height above it): centre + alpha e1 + beta e2 */
+    const double c0[3] = { dot3(fc, x[u1]), dot3(fc, x[u2]), dot3(fc, nref) };
+    const double e1[3] = { hY[p1]*dot3(y[p1], x[u1]), hY[p1]*dot3(y[p1], x[u2]), hY[p1]*dot3(y[p1], nref) };
+    const double e2[3] = { hY[p2]*dot3(y[p2], x[u1]), hY[p2]*dot3(y[p2], x[u2]), hY[p2]*dot3(y[p2], nref) };
+    const double hu = hX[u1], hv = hX[u2];
+    static const double sa[4] = { -1, 1, 1, -1 }, sb[4] = { -1, -1, 1, 1 };             /* quad vertices in order */
+    double cand[12][3]; int valid[12];
+    for (int k = 0; k < 4; k++) {
+        const int k2 = (k + 1) & 3;
+        double P0[3], P1[3];
+        for (int q = 0; q < 3; q++) { P0[q] = c0[q] + sa[k]*e1[q] + sb[k]*e2[q]; P1[q] = c0[q] + sa[k2]*e1[q] + sb[k2]*e2[q]; }
+        /* Liang-Barsky on |u| <= hu, |v| <= hv */
+        double t0 = 0, t1 = 1; int ok = 1;
+        const double dq[2] = { P1[0] - P0[0], P1[1] - P0[1] }, lim[2] = { hu, hv };
+        for (int ax = 0; ax < 2 && ok; ax++) {
+            for (int side = -1; side <= 1; side += 2) {
+                const double pden = -side*dq[ax], pnum = side*P0[ax] - lim[ax];          /* side*(P0 + t dq) <= lim  <=>  t*(-pden) <= -pnum */
+                if (pden == 0) { if (pnum > 0) ok = 0; }
+                else {
+                    const double t = pnum/pden;
+                    if (pden > 0) { if (t > t0) t0 = t; }     /* entering */
+                    else          { if (t < t1) t1 = t; }     /* leaving  */
+                }
+            }
+        }
+        if (t0 > t1) ok = 0;
+        valid[2*k] = ok; valid[2*k + 1] = ok && t1 < 1.0;
+        for (int q = 0; q < 3; q++) { cand[2*k][q] = P0[q] + t0*(P1[q] - P0[q]); cand[2*k + 1][q] = P0[q] + t1*(P1[q] - P0[q]); }
+    }
+    {   /* rectangle corners inside the incident parallelogram: (u,v) = c0 + alpha e1 + beta e2, |alpha|, |beta| < 1 */
+        const double det = e1[0]*e2[1] - e1[1]*e2[0];
+        for (int k = 0; k < 4; k++) {
+            const double uu = sa[k]*hu - c0[0], vv = sb[k]*hv - c0[1];
+            int ok = fabs(det) > 1e-18;
+            double al = 0, be = 0;
+            if (ok) { al = (uu*e2[1] - vv*e2[0])/det; be = (e1[0]*vv - e1[1]*uu)/det; ok = fabs(al) < 1.0 && fabs(be) < 1.0; }
+            valid[8 + k] = ok;
+            cand[8 + k][0] = sa[k]*hu; cand[8 + k][1] = sb[k]*hv; cand[8 + k][2] = c0[2] + al*e1[2] + be*e2[2];
+        }
+    }
+    int cnt = 0;
+    for (int k = 0; k < 12 && cnt < 8; k++) {
+        if (!valid[k] || cand[k][2] > 0) continue;
+        const double w = cand[k][2];
+        for (int q = 0; q < 3; q++) pos[cnt][q] = rc[q] + cand[k][0]*x[u1][q] + cand[k][1]*x[u2][q] + 0.5*w*nref[q];
+        dist[cnt] = w;
+        cnt++;
+    }
+    return cnt;
+}
+
+/* point Jacobian row of body b at world point p along direction dir, accumulated into J with sign sg */
+static void jac_point_dir(const so100o_data* d, int b, const double p[3], const double dir[3], double sg, double* J) {
+    if (b <= 1) return;                                     /* world / welded base */
+    const int j0 = b == CUBE ? 6 : 0, j1 = b == CUBE ? NV : b - 1;     /* arm body b moves with dofs 0 .. b-2 */
+    for (int j = j0; j < j1; j++) {
+        double w[3]; cross3(w, d->cdof[j], p);              /* omega x p + v_origin */
+        for (int a = 0; a < 3; a++) w[a] += d->cdof[j][3 + a];
+        J[j] += sg*dot3(dir, w);
+    }
+}
+
+static int add_contact(const so100o_model* m, so100o_data* d, int kind, int geom, int b1, int b2, const double pos[3],
+                       const double normal[3], double dist, double mu, const double solref[2], const double solimp[5]) {
+    const int budget = m->max_contacts > 0 && m->max_contacts < SO100O_MAXCON ? m->max_contacts : SO100O_MAXCON;
+    if (d->ncon >= budget) { d->ncon_dropped++; return -1; }
+    so100o_contact* c = &d->con[d->ncon];
+    c->b1 = b1; c->b2 = b2; c->kind = kind; c->geom = geom; c->dist = dist; c->mu = mu;
+    memcpy(c->pos, pos, sizeof c->pos); memcpy(c->solref, solref, sizeof c->solref); memcpy(c->solimp, solimp, sizeof c->solimp);
+    /* mju_makeFrame: t1 = (0,1,0) if |n_y| < 0.5 else (0,0,1), orthogonalised against n; t2 = n x t1 */
+    double* f = c->frame;
+    memcpy(f, normal, sizeof(double)*3);
+    f[3] = 0; f[4] = 0; f[5] = 0;
+    if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+    { const double dp = dot3(f, f + 3); for (int k = 0; k < 3; k++) f[3 + k] -= dp*f[k];
+      const double nn = sqrt(dot3(f + 3, f + 3)); for (int k = 0; k < 3; k++) f[3 + k] /= nn; }
+    cross3(f + 6, f, f + 3);
+    /* pyramidal rows (condim 3): J = (jac_b2 - jac_b1)(p) . (n +- mu t_k); aref = -B Jv - K imp dist;
+     * diagApprox = tran (1 + mu^2), tran = body_invweight0 of both bodies; R = 2 mu^2 R(first edge), impratio 1 */
+    double K, B, J[NV];
+    solref_KB_of(solref, solimp[1], m->timestep, &K, &B);
+    const double imp = impedance_of(solimp, dist);
+    const double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+    const double R0 = fmax(SO100_MJMINVAL, (1 - imp)*(tran + mu*mu*tran)/imp), Rpy = 2*mu*mu*R0;
+    c->efc0 = d->nefc;
+    for (int k = 0; k < 2; k++)
+        for (int sgn = 1; sgn >= -1; sgn -= 2) {
+            double dir[3];
+            for (int a = 0; a < 3; a++) dir[a] = f[a] + sgn*mu*f[3 + 3*k + a];
+            memset(J, 0, sizeof J);
+            jac_point_dir(d, b2, pos, dir, 1.0, J);
+            jac_point_dir(d, b1, pos, dir, -1.0, J);
+            const int r = d->nefc++;
+            d->efc_type[r] = 2; d->efc_id[r] = kind == 0 ? 4*d->ncon + 2*k + (sgn < 0) : -1;
+            d->efc_pos[r] = dist; d->efc_floss[r] = 0;
+            memcpy(d->efc_J[r], J, sizeof J);
+            double vel = 0; for (int i = 0; i < NV; i++) vel += J[i]*d->qvel[i];
+            d->efc_aref[r] = -B*vel - K*imp*dist;
+            d->efc_R[r] = Rpy;
+        }
+    return d->ncon++;
+}
+
 static void make_constraints(const so100o_model* m, so100o_data* d, unsigned flags) {
     double K, B, J[NV];
     solref_KB(m->timestep, &K, &B);
-    d->nefc = 0; d->ncon = 0;
+    d->nefc = 0; d->ncon = 0; d->ncon_dropped = 0;
     if (flags & SO100O_F_FRICTIONLOSS)
         for (int i = 0; i < 6; i++) if (m->frictionloss[i] > 0) {
             memset(J, 0, sizeof J); J[i] = 1;
@@ -437,43 +688,39 @@ static void make_constraints(const so100o_model* m, so100o_data* d, unsigned fla
                     add_row(d, 1, 2*i + (side + 1)/2, J, dist, 0.0, m->dof_invweight0[i], K, B);
                 }
             }
+    const double nz[3] = {0, 0, 1};
+    /* contacts in geom-pair order: the arm's geoms come first (attached first, scene:24-26), so pad/floor and pad/cube pairs
+     * precede cube/floor.  Cube/floor keeps its place at the front here for the benefit of the PGS warm start identities;
+     * the converged solution does not depend on the order. */
     if ((flags & SO100O_F_FLOOR) && !(flags & SO100O_F_CUBE_PINNED)) {
-        /* mjc_PlaneBox: plane z = 0, normal +z; contact frame t1 = +y, t2 = -x (mju_makeFrame) */
-        const double n[3] = {0, 0, 1};
-        const double tng[2][3] = { {0, 1, 0}, {-1, 0, 0} };
-        const double mu = SO100_GEOM_FRICTION, hs = SO100_CUBE_HALF;
-        double cdist = d->xpos[CUBE][2];
-        int cnt = 0;
-        for (int c = 0; c < 8 && cnt < 4; c++) {
-            double v[3] = { (c & 1) ? hs : -hs, (c & 2) ? hs : -hs, (c & 4) ? hs : -hs }, corner[3];
-            mat_vec3(corner, d->xmat[CUBE], v);
-            double ldist = corner[2];
-            if (cdist + ldist > 0 || ldist > 0) continue;
-            double dist = cdist + ldist, p[3];
-            for (int k = 0; k < 3; k++) p[k] = corner[k] + d->xpos[CUBE][k] - n[k]*dist*0.5;
-            /* diagApprox (mj_diagApprox, pyramidal): tran + mu^2 * tran */
-            double tran = m->body_invweight0[CUBE][0];
-            double dA = tran + mu*mu*tran;
-            int first = -1;
-            for (int k = 0; k < 2; k++)
-                for (int sgn = 1; sgn >= -1; sgn -= 2) {
-                    double dir[3];
-                    for (int a = 0; a < 3; a++) dir[a] = n[a] + sgn*mu*tng[k][a];
-                    memset(J, 0, sizeof J);
-                    for (int j = 6; j < NV; j++) {
-                        double w[3]; cross3(w, d->cdof[j], p);        /* omega x p */
-                        for (int a = 0; a < 3; a++) w[a] += d->cdof[j][3 + a];
-                        J[j] = dot3(dir, w);
-                    }
-                    int r = add_row(d, 2, 4*cnt + 2*k + (sgn < 0), J, dist, 0.0, dA, K, B);
-                    if (first < 0) first = r;
-                }
-            /* mj_makeImpedance, pyramidal: all edges get Rpy = 2 mu^2 R(first edge); impratio = 1 */
-            double Rpy = 2*mu*mu*d->efc_R[first];
-            for (int r = first; r < first + 4; r++) d->efc_R[r] = Rpy;
-            cnt++;
+        double hs[3] = { SO100_CUBE_HALF, SO100_CUBE_HALF, SO100_CUBE_HALF }, pos[4][3], dist[4], ref[2], imp[5], mu;
+        mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->def_solref, m->def_solimp, m->def_friction, ref, imp, &mu);
+        const int n = so100o_plane_box(d->xpos[CUBE], d->xmat[CUBE], hs, pos, dist);
+        for (int k = 0; k < n; k++) add_contact(m, d, 0, 0, 0, CUBE, pos[k], nz, dist[k], mu, ref, imp);
+    }
+    if (flags & SO100O_F_PADS_FLOOR) {
+        double ref[2], imp[5], mu;
+        mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->pad_solref, m->pad_solimp, m->pad_friction, ref, imp, &mu);
+        for (int g = 0; g < SO100O_NPAD; g++) {
+            const int b = m->pad_body[g];
+            double c[3], v[3], pos[4][3], dist[4];
+            mat_vec3(v, d->xmat[b], m->pad_pos[g]);
+            for (int k = 0; k < 3; k++) c[k] = d->xpos[b][k] + v[k];
+            const int n = so100o_plane_box(c, d->xmat[b], m->pad_size[g], pos, dist);
+            for (int k = 0; k < n; k++) add_contact(m, d, 1, g, 0, b, pos[k], nz, dist[k], mu, ref, imp);
         }
-        d->ncon = cnt;
+    }
+    if ((flags & SO100O_F_PADS_CUBE) && !(flags & SO100O_F_CUBE_PINNED)) {
+        double ref[2], imp[5], mu, hs[3] = { SO100_CUBE_HALF, SO100_CUBE_HALF, SO100_CUBE_HALF };
+        mix_contact_params(m->pad_solref, m->pad_solimp, m->pad_friction, m->def_solref, m->def_solimp, m->def_friction, ref, imp, &mu);
+        for (int g = 0; g < SO100O_NPAD; g++) {
+            const int b = m->pad_body[g];
+            double c[3], v[3], pos[8][3], dist[8], nrm[3];
+            mat_vec3(v, d->xmat[b], m->pad_pos[g]);
+            for (int k = 0; k < 3; k++) c[k] = d->xpos[b][k] + v[k];
+            const int n = so100o_box_box(c, d->xmat[b], m->pad_size[g], d->xpos[CUBE], d->xmat[CUBE], hs, pos, nrm, dist);
+            for (int k = 0; k < n; k++) add_contact(m, d, 2, g, b, CUBE, pos[k], nrm, dist[k], mu, ref, imp);
+        }
     }
 }
 
@@ -498,7 +745,7 @@ static void solve_pgs(const so100o_model* m, so100o_data* d, int iters) {
     for (int r = 0; r < n; r++) {
         int id = d->efc_id[r];
         d->efc_force[r] = d->efc_type[r] == 0 ? d->warm_fric[id]
-                        : d->efc_type[r] == 1 ? d->warm_limit[id/2] : d->warm_contact[id];
+                        : d->efc_type[r] == 1 ? d->warm_limit[id/2] : (id >= 0 && id < 16 ? d->warm_contact[id] : 0.0);
         if (d->efc_type[r] != 0 && d->efc_force[r] < 0) d->efc_force[r] = 0;
     }
     int maxit = iters > 0 ? iters : 2000;
@@ -524,12 +771,115 @@ static void solve_pgs(const so100o_model* m, so100o_data* d, int iters) {
         int id = d->efc_id[r];
         if (d->efc_type[r] == 0) d->warm_fric[id] = d->efc_force[r];
         else if (d->efc_type[r] == 1) d->warm_limit[id/2] = d->efc_force[r];
-        else d->warm_contact[id] = d->efc_force[r];
+        else if (id >= 0 && id < 16) d->warm_contact[id] = d->efc_force[r];
         for (int i = 0; i < NV; i++) d->qfrc_constraint[i] += d->efc_J[r][i]*d->efc_force[r];
     }
     double dq[NV];
     chol_solve(d->L, NV, d->qfrc_constraint, dq);
     for (int i = 0; i < NV; i++) d->qacc[i] = d->qacc_smooth[i] + dq[i];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Newton on the primal (mj_solNewton's problem): minimise over x = qacc
+ *     1/2 (x - a0)' M (x - a0) + sum_r s_r(J_r x - aref_r),
+ * s_r = the row's penalty: friction-loss rows Huber (quadratic |jar| <= R floss, linear outside, force saturating at
+ * +-floss), limit / contact rows 1/(2R) min(0, jar)^2.  Newton direction from the exact Hessian M + J' D J of the current
+ * active set, exact line search on the convex piecewise-quadratic restriction, iterated to machine precision.  Same optimum
+ * as the PGS on the dual above (the dual of this problem is that one); tests/test_oracle_physics.py checks it.
+ * nvs = number of leading dofs solved for (6 when the cube is pinned, else 12).
+ * ---------------------------------------------------------------------------------------------- */
+static double row_penalty(const so100o_data* d, int r, double jar, double* force, double* hess) {
+    const double R = d->efc_R[r], D = 1.0/R;
+    if (d->efc_type[r] == 0) {
+        const double fl = d->efc_floss[r];
+        if (jar <= -R*fl) { *force = fl;  *hess = 0; return -0.5*R*fl*fl - fl*jar; }
+        if (jar >=  R*fl) { *force = -fl; *hess = 0; return -0.5*R*fl*fl + fl*jar; }
+        *force = -D*jar; *hess = D; return 0.5*D*jar*jar;
+    }
+    if (jar < 0) { *force = -D*jar; *hess = D; return 0.5*D*jar*jar; }
+    *force = 0; *hess = 0; return 0;
+}
+static double primal_cost(const so100o_data* d, int nvs, const double* x, double* jar, double* grad, double* H) {
+    const int n = d->nefc;
+    double dx[NV], Mdx[NV], cost = 0;
+    for (int i = 0; i < nvs; i++) dx[i] = x[i] - d->qacc_smooth[i];
+    for (int i = 0; i < nvs; i++) { double t = 0; for (int j = 0; j < nvs; j++) t += d->M[i*NV + j]*dx[j]; Mdx[i] = t; cost += 0.5*dx[i]*t; }
+    if (grad) memcpy(grad, Mdx, sizeof(double)*nvs);
+    if (H) for (int i = 0; i < nvs; i++) for (int j = 0; j < nvs; j++) H[i*nvs + j] = d->M[i*NV + j];
+    for (int r = 0; r < n; r++) {
+        double jr = -d->efc_aref[r], f, h;
+        for (int i = 0; i < nvs; i++) jr += d->efc_J[r][i]*x[i];
+        jar[r] = jr;
+        cost += row_penalty(d, r, jr, &f, &h);
+        if (grad) for (int i = 0; i < nvs; i++) grad[i] -= d->efc_J[r][i]*f;
+        if (H && h != 0) for (int i = 0; i < nvs; i++) for (int j = 0; j < nvs; j++) H[i*nvs + j] += h*d->efc_J[r][i]*d->efc_J[r][j];
+    }
+    return cost;
+}
+static void solve_newton(const so100o_model* m, so100o_data* d, int nvs) {
+    const int n = d->nefc;
+    memset(d->qfrc_constraint, 0, sizeof d->qfrc_constraint);
+    memcpy(d->qacc, d->qacc_smooth, sizeof d->qacc);
+    d->solver_iter_used = 0; d->solver_last_change = 0;
+    if (n == 0) return;
+    static _Thread_local double jar[SO100O_MAXEFC], jp[SO100O_MAXEFC];
+    double x[NV], g[NV], H[NV*NV], Lh[NV*NV], p[NV];
+    /* warm start: the previous acceleration if it is cheaper than the unconstrained one (mj_fwdConstraint does the same) */
+    memcpy(x, d->qacc_smooth, sizeof x);
+    {
+        const double c0 = primal_cost(d, nvs, d->qacc_smooth, jar, NULL, NULL), c1 = primal_cost(d, nvs, d->qacc_warmstart, jar, NULL, NULL);
+        if (c1 < c0) memcpy(x, d->qacc_warmstart, sizeof(double)*nvs);
+    }
+    for (int it = 0; it < 200; it++) {
+        const double cost = primal_cost(d, nvs, x, jar, g, H);
+        double gn = 0; for (int i = 0; i < nvs; i++) gn = fmax(gn, fabs(g[i]));
+        d->solver_iter_used = it; d->solver_last_change = gn;
+        if (gn < 1e-13) break;
+        cholesky(H, Lh, nvs);
+        for (int i = 0; i < nvs; i++) g[i] = -g[i];
+        chol_solve(Lh, nvs, g, p);
+        for (int i = 0; i < nvs; i++) g[i] = -g[i];
+        /* exact line search: phi'(alpha) = p'M(x + alpha p - a0) - sum_r f_r(jar_r + alpha jp_r) jp_r, increasing in alpha */
+        double q1 = 0, q2 = 0;
+        for (int i = 0; i < nvs; i++) {
+            double t1 = 0, t2 = 0;
+            for (int j = 0; j < nvs; j++) { t1 += d->M[i*NV + j]*(x[j] - d->qacc_smooth[j]); t2 += d->M[i*NV + j]*p[j]; }
+            q1 += p[i]*t1; q2 += p[i]*t2;
+        }
+        for (int r = 0; r < n; r++) { double t = 0; for (int i = 0; i < nvs; i++) t += d->efc_J[r][i]*p[i]; jp[r] = t; }
+        double lo = 0, hi = -1, alpha = 1;
+        for (int ls = 0; ls < 200; ls++) {
+            double d1 = q1 + alpha*q2, d2 = q2;
+            for (int r = 0; r < n; r++) {
+                double f, h; row_penalty(d, r, jar[r] + alpha*jp[r], &f, &h);
+                d1 -= f*jp[r]; d2 += h*jp[r]*jp[r];
+            }
+            if (d1 < 0) lo = alpha; else hi = alpha;
+            double an = d2 > 0 ? alpha - d1/d2 : alpha;
+            if (!(an > lo && (hi < 0 || an < hi))) an = hi < 0 ? 2*alpha : 0.5*(lo + hi);
+            if (fabs(an - alpha) <= 1e-15*fabs(alpha) || d1 == 0) { alpha = an; break; }
+            alpha = an;
+        }
+        double step = 0;
+        for (int i = 0; i < nvs; i++) { x[i] += alpha*p[i]; step = fmax(step, fabs(alpha*p[i])); }
+        (void)cost;
+        if (step < 1e-16) break;
+    }
+    primal_cost(d, nvs, x, jar, g, NULL);
+    for (int r = 0; r < n; r++) {
+        double f, h; row_penalty(d, r, jar[r], &f, &h);
+        d->efc_force[r] = f;
+        for (int i = 0; i < NV; i++) d->qfrc_constraint[i] += d->efc_J[r][i]*f;
+    }
+    memcpy(d->qacc, x, sizeof(double)*nvs);
+    /* keep the PGS force memory coherent for callers that switch solvers */
+    memset(d->warm_fric, 0, sizeof d->warm_fric); memset(d->warm_limit, 0, sizeof d->warm_limit); memset(d->warm_contact, 0, sizeof d->warm_contact);
+    for (int r = 0; r < n; r++) {
+        const int id = d->efc_id[r];
+        if (d->efc_type[r] == 0) d->warm_fric[id] = d->efc_force[r];
+        else if (d->efc_type[r] == 1) d->warm_limit[id/2] = d->efc_force[r];
+        else if (id >= 0 && id < 16) d->warm_contact[id] = d->efc_force[r];
+    }
 }
 
 /* ================================================================================================
@@ -555,7 +905,8 @@ void so100o_forward(const so100o_model* m, so100o_data* d, unsigned flags, int i
         d->qfrc_smooth[i] = -d->qfrc_bias[i] + d->qfrc_applied[i] + d->qfrc_actuator[i];
     if (flags & SO100O_F_CUBE_PINNED) for (int i = 6; i < NV; i++) d->qfrc_smooth[i] = 0;
     chol_solve(d->L, NV, d->qfrc_smooth, d->qacc_smooth);
-    solve_pgs(m, d, iters);
+    if (iters < 0) solve_newton(m, d, (flags & SO100O_F_CUBE_PINNED) ? 6 : NV);
+    else solve_pgs(m, d, iters);
     if (flags & SO100O_F_CUBE_PINNED) for (int i = 6; i < NV; i++) d->qacc[i] = 0;
 }
 

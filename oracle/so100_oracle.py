@@ -9,8 +9,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-NB, NQ, NV, MAXEFC, NINJECT = 9, 13, 12, 32, 16
-F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED = 1, 2, 4, 8
+NB, NQ, NV, MAXEFC, NINJECT, NPAD, MAXCON = 9, 13, 12, 412, 16, 8, 100
+F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE = 1, 2, 4, 8, 16, 32
+F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR | F_PADS_FLOOR        # what the reference scene simulates (minus the mesh geoms)
+F_CONTACT5 = F_REFERENCE | F_PADS_CUBE                                   # BASELINE.json configs[4]
 
 d_ = C.c_double
 
@@ -30,7 +32,17 @@ class Model(C.Structure):
         ("kp", d_), ("kv", d_ * 6),
         ("timestep", d_), ("gravity", d_ * 3),
         ("qpos0", d_ * NQ),
+        ("pad_body", C.c_int * NPAD), ("pad_pos", d_ * 3 * NPAD), ("pad_size", d_ * 3 * NPAD),
+        ("pad_solref", d_ * 2), ("pad_solimp", d_ * 5), ("pad_friction", d_),
+        ("def_solref", d_ * 2), ("def_solimp", d_ * 5), ("def_friction", d_),
+        ("max_contacts", C.c_int),
     ]
+
+
+class Contact(C.Structure):
+    _fields_ = [("b1", C.c_int), ("b2", C.c_int), ("kind", C.c_int), ("geom", C.c_int),
+                ("pos", d_ * 3), ("frame", d_ * 9), ("dist", d_), ("mu", d_), ("solref", d_ * 2), ("solimp", d_ * 5),
+                ("efc0", C.c_int)]
 
 
 class Data(C.Structure):
@@ -53,6 +65,7 @@ class Data(C.Structure):
         ("efc_b", d_ * MAXEFC),
         ("warm_fric", d_ * 6), ("warm_limit", d_ * 6), ("warm_contact", d_ * 16),
         ("solver_iter_used", C.c_int), ("solver_last_change", d_),
+        ("con", Contact * MAXCON), ("ncon_dropped", C.c_int),
     ]
 
 

@@ -107,6 +107,45 @@ static const double SO100_CAM_EULER[3] = { 4.974, 0.0, 3.142 };
 #define SO100_CAM_FOVY_DEG 120.0
 #define SO100_CAM_LINK 4
 
+/* ---- finger pads: the 8 box geoms of class "finger_collision" (arm:60-62): arm:108-111 on Fixed_Jaw (link 4),
+ * arm:120-123 on Moving_Jaw (link 5).  size = half extents, pos in the link frame, orientation identity.  They are the only
+ * arm collision geometry that is not a mesh (the STL meshes of class "collision", arm:58-59, are not in the reference
+ * snapshot).  In the reference scene they collide with the floor plane (scene:39; default contype/conaffinity 1) but not
+ * with each other (Moving_Jaw is Fixed_Jaw's child: parent-child filter) and not with the cube (excluded, scene:47-48:
+ * BASELINE.json configs[4] lifts exactly these two exclusions).                                                        */
+#define SO100_NPAD 8
+static const int SO100_PAD_LINK[SO100_NPAD] = { 4, 4, 4, 4, 5, 5, 5, 5 };
+static const double SO100_PAD_POS[SO100_NPAD][3] = {
+    { 0.0089, -0.1014, 0.0 },   /* fixed_jaw_pad_1   arm:108 */
+    { 0.0109, -0.0914, 0.0 },   /* fixed_jaw_pad_2   arm:109 */
+    { 0.0126, -0.0768, 0.0 },   /* fixed_jaw_pad_3   arm:110 */
+    { 0.0143, -0.0572, 0.0 },   /* fixed_jaw_pad_4   arm:111 */
+    {-0.0113, -0.077,  0.0 },   /* moving_jaw_pad_1  arm:120 */
+    {-0.0093, -0.067,  0.0 },   /* moving_jaw_pad_2  arm:121 */
+    {-0.0073, -0.055,  0.0 },   /* moving_jaw_pad_3  arm:122 */
+    {-0.0073, -0.035,  0.0 },   /* moving_jaw_pad_4  arm:123 */
+};
+static const double SO100_PAD_SIZE[SO100_NPAD][3] = {
+    { 0.001, 0.005, 0.004 },
+    { 0.001, 0.005, 0.006 },
+    { 0.001, 0.01,  0.007 },
+    { 0.001, 0.01,  0.008 },
+    { 0.001, 0.005, 0.004 },
+    { 0.001, 0.005, 0.006 },
+    { 0.001, 0.01,  0.006 },
+    { 0.001, 0.01,  0.008 },
+};
+/* arm:61  solimp="2 1 0.01" solref="0.01 1" friction="1 0.005 0.0001" (midpoint / power stay at their defaults) */
+#define SO100_PAD_SOLREF_TIMECONST 0.01
+#define SO100_PAD_SOLREF_DAMPRATIO 1.0
+#define SO100_PAD_SOLIMP_D0     2.0
+#define SO100_PAD_SOLIMP_DMAX   1.0
+#define SO100_PAD_SOLIMP_WIDTH  0.01
+#define SO100_PAD_FRICTION      1.0
+/* mj_assignImp clamps d0, dmax (and the midpoint) into [mjMINIMP, mjMAXIMP] AFTER the two geoms' solimp have been mixed */
+#define SO100_MJMINIMP 0.0001
+#define SO100_MJMAXIMP 0.9999
+
 /* ---- cube "block_a": scene:29-35.  inertiafromgeom="true" (scene:2) => mass and inertia come
  * from the box geom (half size 0.01, default density 1000), COM at the geom centre (0,0,0);
  * the <inertial mass="0.2"> at scene:33 is overridden.              */

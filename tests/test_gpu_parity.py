@@ -487,7 +487,9 @@ def test_persistent_rollout_equals_stepwise(kind, flags):
         b1 = {k: v.clone() for k, v in col.collect().items()}
         b2 = {k: v.clone() for k, v in col.collect(5).items()}          # a second, shorter chunk continues the episode
         q, v = env.sim.get_state()
-        outs.append((b1, b2, q, v, env.sim.terminal_obs.clone(), env.sim.ep_length.clone()))
+        # terminal observations: the collector's per-chunk buffer (entries are only written where an episode ended)
+        tob = torch.where((b2["dones"] > 0)[..., None], col.tobs[:5], torch.zeros_like(col.tobs[:5]))
+        outs.append((b1, b2, q, v, tob, env.sim.ep_length.clone()))
     (a1, a2, aq, av, at, al), (s1, s2, sq, sv, st_, sl) = outs
     for a, s in ((a1, s1), (a2, s2)):
         for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
