@@ -631,8 +631,12 @@ static void jac_point_dir(const so100o_data* d, int b, const double p[3], const 
 
 static int add_contact(const so100o_model* m, so100o_data* d, int kind, int geom, int b1, int b2, const double pos[3],
                        const double normal[3], double dist, double mu, const double solref[2], const double solimp[5]) {
-    const int budget = m->max_contacts > 0 && m->max_contacts < SO100O_MAXCON ? m->max_contacts : SO100O_MAXCON;
-    if (d->ncon >= budget) { d->ncon_dropped++; return -1; }
+    /* the product's contact budget (csrc/so100_contact.hpp: MAXPADC) counts PAD contacts, in detection order pad/floor by
+     * pad then pad/cube by pad; the cube's own <= 4 floor contacts are outside it */
+    if (kind != 0) {
+        int npad = 0; for (int i = 0; i < d->ncon; i++) npad += d->con[i].kind != 0;
+        if ((m->max_contacts > 0 && npad >= m->max_contacts) || d->ncon >= SO100O_MAXCON) { d->ncon_dropped++; return -1; }
+    }
     so100o_contact* c = &d->con[d->ncon];
     c->b1 = b1; c->b2 = b2; c->kind = kind; c->geom = geom; c->dist = dist; c->mu = mu;
     memcpy(c->pos, pos, sizeof c->pos); memcpy(c->solref, solref, sizeof c->solref); memcpy(c->solimp, solimp, sizeof c->solimp);
@@ -860,10 +864,10 @@ static void solve_newton(const so100o_model* m, so100o_data* d, int nvs) {
             if (fabs(an - alpha) <= 1e-15*fabs(alpha) || d1 == 0) { alpha = an; break; }
             alpha = an;
         }
-        double step = 0;
-        for (int i = 0; i < nvs; i++) { x[i] += alpha*p[i]; step = fmax(step, fabs(alpha*p[i])); }
+        double step = 0, xm = 0;
+        for (int i = 0; i < nvs; i++) { x[i] += alpha*p[i]; step = fmax(step, fabs(alpha*p[i])); xm = fmax(xm, fabs(x[i])); }
         (void)cost;
-        if (step < 1e-16) break;
+        if (step < 1e-15*(1.0 + xm)) break;                  /* the iterate no longer moves: machine precision */
     }
     primal_cost(d, nvs, x, jar, g, NULL);
     for (int r = 0; r < n; r++) {

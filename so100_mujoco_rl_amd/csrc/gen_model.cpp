@@ -117,6 +117,37 @@ int main(int argc, char** argv) {
             for (int r=0;r<N;r++) if (r!=c) { double f=A[r][c]; for (int j=0;j<2*N;j++) A[r][j]-=f*A[c][j]; } }
         for (int i=0;i<N;i++) { M0[i]=M[i][i]; INVW0[i]=A[i][N+i]; KV[i]=SO100_ACT_DAMPRATIO*2.0*std::sqrt(SO100_ACT_KP*M0[i]); }
     }
+    // body_invweight0 of the two jaw links (mj_setConst): mean diagonal of J M^-1 J^T, J = translational Jacobian of the
+    // link's COM at qpos0 (only the translational weight enters the diagApprox of a condim-3 pyramidal contact)
+    double INVW_TRAN[N];
+    {
+        double Ainv[N][N];
+        {   double A[N][2*N];
+            for (int i=0;i<N;i++) for (int j=0;j<N;j++) { A[i][j]=M[i][j]; A[i][N+j]=(i==j); }
+            for (int c=0;c<N;c++) { double p=A[c][c]; for (int j=0;j<2*N;j++) A[c][j]/=p;
+                for (int r=0;r<N;r++) if (r!=c) { double f=A[r][c]; for (int j=0;j<2*N;j++) A[r][j]-=f*A[c][j]; } }
+            for (int i=0;i<N;i++) for (int j=0;j<N;j++) Ainv[i][j]=A[i][N+j]; }
+        for (int b = 0; b < N; b++) {
+            double cw[3], t[3]; mv(t, Rw[b], COM[b]); for (int a=0;a<3;a++) cw[a] = xw[b][a]+t[a];
+            double J[3][N] = {{0}};
+            for (int j = 0; j <= b; j++) {
+                double r[3] = { cw[0]-xw[j][0], cw[1]-xw[j][1], cw[2]-xw[j][2] };
+                J[0][j] = axw[j][1]*r[2]-axw[j][2]*r[1]; J[1][j] = axw[j][2]*r[0]-axw[j][0]*r[2]; J[2][j] = axw[j][0]*r[1]-axw[j][1]*r[0];
+            }
+            double tr = 0;
+            for (int a=0;a<3;a++) for (int i=0;i<N;i++) for (int j=0;j<N;j++) tr += J[a][i]*Ainv[i][j]*J[a][j];
+            INVW_TRAN[b] = tr/3.0;
+        }
+    }
+    // contact parameters of every pair that involves a finger pad (pad/floor, pad/cube): mj_contactParam mixes the two geoms'
+    // solref / solimp 1:1 (equal priority, solmix 1), friction = max; mj_assignImp then clamps d0, dmax into [1e-4, 0.9999]
+    auto clampimp = [](double v) { return v < SO100_MJMINIMP ? SO100_MJMINIMP : (v > SO100_MJMAXIMP ? SO100_MJMAXIMP : v); };
+    double ptc = 0.5*(SO100_PAD_SOLREF_TIMECONST + SO100_SOLREF_TIMECONST), pdr = 0.5*(SO100_PAD_SOLREF_DAMPRATIO + SO100_SOLREF_DAMPRATIO);
+    double pd0 = clampimp(0.5*(SO100_PAD_SOLIMP_D0 + SO100_SOLIMP_D0)), pdm = clampimp(0.5*(SO100_PAD_SOLIMP_DMAX + SO100_SOLIMP_DMAX));
+    double pw = 0.5*(SO100_PAD_SOLIMP_WIDTH + SO100_SOLIMP_WIDTH);
+    if (ptc < 2*SO100_TIMESTEP) ptc = 2*SO100_TIMESTEP;
+    double PK = 1.0/(pdm*pdm*ptc*ptc*pdr*pdr), PB = 2.0/(pdm*ptc);
+    double pmu = SO100_PAD_FRICTION > SO100_GEOM_FRICTION ? SO100_PAD_FRICTION : SO100_GEOM_FRICTION;
     double tc = SO100_SOLREF_TIMECONST; if (tc < 2*SO100_TIMESTEP) tc = 2*SO100_TIMESTEP;
     double K = 1.0/(SO100_SOLIMP_DMAX*SO100_SOLIMP_DMAX*tc*tc*SO100_SOLREF_DAMPRATIO*SO100_SOLREF_DAMPRATIO);
     double B = 2.0/(SO100_SOLIMP_DMAX*tc);
@@ -151,6 +182,14 @@ int main(int argc, char** argv) {
     std::fprintf(f, "static constexpr double CUBE_MASS = %.17g, CUBE_INERTIA = %.17g, CUBE_HALF = %.17g, GEOM_FRICTION = %.17g;\n", cm, ci, (double)SO100_CUBE_HALF, (double)SO100_GEOM_FRICTION);
     std::fprintf(f, "static constexpr double CAM_FOVY_DEG = %.17g;\n", (double)SO100_CAM_FOVY_DEG);
     std::fprintf(f, "static constexpr int CAM_LINK = %d;\n", SO100_CAM_LINK);
+    std::fprintf(f, "// finger pads (box geoms on links 4 and 5) and the contact parameters of pairs that involve one\n");
+    std::fprintf(f, "static constexpr int NPAD = %d;\n", SO100_NPAD);
+    std::fprintf(f, "static constexpr int PAD_LINK[%d] = { %d, %d, %d, %d, %d, %d, %d, %d };\n", SO100_NPAD, SO100_PAD_LINK[0], SO100_PAD_LINK[1], SO100_PAD_LINK[2],
+                 SO100_PAD_LINK[3], SO100_PAD_LINK[4], SO100_PAD_LINK[5], SO100_PAD_LINK[6], SO100_PAD_LINK[7]);
+    emit(f, "PAD_POS", &SO100_PAD_POS[0][0], SO100_NPAD, 3);
+    emit(f, "PAD_SIZE", &SO100_PAD_SIZE[0][0], SO100_NPAD, 3);
+    emit1(f, "LINK_INVWEIGHT_TRAN", INVW_TRAN, N);
+    std::fprintf(f, "static constexpr double PADC_K = %.17g, PADC_B = %.17g, PADC_D0 = %.17g, PADC_DMAX = %.17g, PADC_WIDTH = %.17g, PADC_MU = %.17g;\n", PK, PB, pd0, pdm, pw, pmu);
     std::fprintf(f, "}  // namespace so100g\n");
     std::fclose(f);
     return 0;

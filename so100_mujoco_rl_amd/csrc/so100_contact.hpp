@@ -1,0 +1,824 @@
+// so100_contact.hpp -- finger-pad contacts of the so100 gripper: pad/floor and pad/cube.
+//
+// Reference geometry: the 8 box geoms of class "finger_collision" on Fixed_Jaw / Moving_Jaw (arm:108-111, 120-123) with the
+// contact parameters of arm:61 (solimp "2 1 0.01", solref "0.01 1", friction 1), the floor plane (scene:39), the cube
+// (scene:32).  In the reference scene the pads collide with the floor (F_PADS_FLOOR: part of the reference physics) but
+// not with the cube (scene:47-48 exclude block_a against both jaws); BASELINE.json configs[4] lifts exactly that exclusion
+// (F_PADS_CUBE).  MuJoCo stages restated: mj_collision narrowphase
+// (mjc_PlaneBox; a box-box routine in the manner of mjc_BoxBox: 15-axis separating-axis test, then face clipping or an
+// edge-edge point), mj_contactParam's 1:1 mixing of solref / solimp with mj_assignImp's clamp, pyramidal rows (condim 3),
+// and the constraint solve.  Same algorithm, slot order and constants as oracle/so100_oracle.c (the checker), in fp32.
+//
+// Solver.  Contact rows are general Jacobian rows over the arm's 6 dofs (and the cube's 6 when a pad touches the cube), so
+// the joint-space block PGS of so100_physics.hpp (rows +-e_i only) does not apply.  A lane that has pad contacts solves its
+// whole substep in the PRIMAL instead, like MuJoCo's default Newton solver and like the cube/floor block of so100_cube.hpp:
+//     minimise over x = qacc   1/2 x'Mx - x'tau  (+ the cube's 1/2 m |x_l - a0|^2 + 1/2 I |x_a|^2)  +  sum_r s_r(J_r x - aref_r)
+// with s_r the row penalties (friction loss: Huber; limits and pyramid edges: one-sided quadratic), Newton steps on the
+// exact Hessian M + J'DJ of the current active set (6 x 6, or 12 x 12 when arm and cube are coupled), full step when the
+// quadratic model holds, exact line search otherwise.  Lanes without pad contacts keep the block PGS + separate cube solve.
+// Contact Jacobians are never stored: a row's J x is the edge direction dotted with the point acceleration of the link's
+// spatial acceleration, and J'f is the contact wrench projected on the joint axes (world FK of the 6 joint frames).
+//
+// Contact records live in a small per-env store: LDS [record][lane] in the multi-wave kernels (detection on one wave, solve
+// on another), a private array in the one-wave kernel and on the host (tests/_hostcheck).  Budget: MAXC contacts per env;
+// further contacts are dropped in detection order (cube/floor, pad/floor by pad, pad/cube by pad) and counted.
+#pragma once
+#include "so100_cube.hpp"
+#if !defined(__HIPCC__)
+#include <cstdio>
+#endif
+
+namespace so100 {
+
+enum : unsigned { F_PADS_FLOOR = 16u, F_PADS_CUBE = 32u };
+
+constexpr int MAXPADC = 16;                  // budget of PAD contacts per env (oracle: model.max_contacts); detection order = pad/floor
+                                             // by pad, then pad/cube by pad; further ones are dropped and counted
+constexpr int MAXC = MAXPADC + 4;            // + the cube's <= 4 floor contacts, which join the list when a pad touches the cube
+constexpr int CF = 12;                       // floats per contact record
+enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY, C_VZ };
+// C_P point (world, midway between the surfaces), C_N normal geom1 -> geom2 (the tangents follow from it: mju_makeFrame),
+// C_KD = K imp dist, C_RINV = 1/R of the 4 edge rows, C_V = B * relative point velocity (the velocity part of -aref),
+// C_KIND: 0 cube/floor, 1 / 2 pad/floor on link 4 / 5, 3 / 4 pad/cube with the pad on link 4 / 5
+
+template <typename T> struct ContactsPriv {                 // one env's records in a private array
+    T a[MAXC*CF]; int n = 0, dropped = 0;
+    SO100_HD T get(int s, int f) const { return a[s*CF + f]; }
+    SO100_HD void set(int s, int f, T v) { a[s*CF + f] = v; }
+};
+template <typename T> struct ContactsLds {                  // [record][field][lane] image shared by the waves of a workgroup
+    T* base; int lane; int n = 0, dropped = 0;
+    SO100_HD T get(int s, int f) const { return base[(s*CF + f)*64 + lane]; }
+    SO100_HD void set(int s, int f, T v) { base[(s*CF + f)*64 + lane] = v; }
+};
+
+// ---- world-frame kinematics of the six joint frames (axis z_k, origin o_k) and of the two jaw links ------------------------
+template <typename T> struct WorldFK { T z[6][3], o[6][3], R4[9], R5[9]; };
+template <int K, typename T> SO100_HD void wfk_step(const T s[6], const T c[6], T pos[3], T R[9], WorldFK<T>& W) {
+    fk_link<K>(s, c, pos, R);
+    constexpr int AX = so100g::LINK_AXIS[K];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { W.z[K][i] = R[3*i + AX]; W.o[K][i] = pos[i]; }
+}
+template <typename T> SO100_HD void world_fk(const T s[6], const T c[6], WorldFK<T>& W) {
+    T pos[3] = { T(0), T(0), T(0) };
+    T R[9] = { T(1), T(0), T(0), T(0), T(1), T(0), T(0), T(0), T(1) };
+    wfk_step<0>(s, c, pos, R, W); wfk_step<1>(s, c, pos, R, W); wfk_step<2>(s, c, pos, R, W); wfk_step<3>(s, c, pos, R, W);
+    wfk_step<4>(s, c, pos, R, W);
+#pragma unroll
+    for (int i = 0; i < 9; i++) W.R4[i] = R[i];
+    wfk_step<5>(s, c, pos, R, W);
+#pragma unroll
+    for (int i = 0; i < 9; i++) W.R5[i] = R[i];
+}
+// spatial motion (about the world origin) of links 4 and 5 produced by the joint-space vector x (velocities or accelerations)
+template <typename T> struct Spatial { T a[3], b[3]; };      // angular part, linear part at the origin
+template <typename T> SO100_HD void link_spatial(const WorldFK<T>& W, const T x[6], Spatial<T>& S4, Spatial<T>& S5) {
+    T a[3] = { T(0), T(0), T(0) }, b[3] = { T(0), T(0), T(0) };
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T oz[3]; cross(W.o[i], W.z[i], oz);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { a[k] += x[i]*W.z[i][k]; b[k] += x[i]*oz[k]; }
+        if (i == 4) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { S4.a[k] = a[k]; S4.b[k] = b[k]; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { S5.a[k] = a[k]; S5.b[k] = b[k]; }
+}
+template <typename T> SO100_HD void point_motion(const Spatial<T>& S, const T p[3], T out[3]) {
+    T t[3]; cross(S.a, p, t);
+    out[0] = t[0] + S.b[0]; out[1] = t[1] + S.b[1]; out[2] = t[2] + S.b[2];
+}
+
+// ---- contact parameters ------------------------------------------------------------------------------------------------
+// impedance d(r) of the pad-involved pairs: solimp (0.9999, 0.975, 0.0055, 0.5, 2) after mixing + clamp (so100_model_gen.h)
+template <typename T> SO100_HD T impedance_pad(T r) {
+    const T x = r * T(1.0/so100g::PADC_WIDTH);
+    const T d0 = T(so100g::PADC_D0), dm = T(so100g::PADC_DMAX);
+    if (x >= T(1)) return dm;
+    if (x <= T(0)) return d0;
+    const T y = x <= T(0.5) ? T(2)*x*x : T(1) - T(2)*(T(1) - x)*(T(1) - x);
+    return d0 + y*(dm - d0);
+}
+
+// mju_makeFrame: t1 = e_y unless |n_y| >= 0.5 (then e_z), orthogonalised against n and normalised; t2 = n x t1
+template <typename T> SO100_HD void contact_frame(const T n[3], T t1[3], T t2[3]) {
+    const bool usey = n[1] < T(0.5) && n[1] > T(-0.5);
+    const T dp = usey ? n[1] : n[2];
+    t1[0] = -dp*n[0]; t1[1] = (usey ? T(1) : T(0)) - dp*n[1]; t1[2] = (usey ? T(0) : T(1)) - dp*n[2];
+    const T rn = trcp(tsqrt(dot(t1, t1)));
+    t1[0] *= rn; t1[1] *= rn; t1[2] *= rn;
+    cross(n, t1, t2);
+}
+
+// append one contact (returns false when the pad budget is exhausted).  vrel = relative point velocity geom2 - geom1.
+template <typename T, class Store>
+SO100_HD bool contact_add(Store& cs, int kind, const T p[3], const T n[3], T dist, const T vrel[3]) {
+    if (kind != 0 && cs.n >= MAXPADC) { cs.dropped++; return false; }
+    if (cs.n >= MAXC) { cs.dropped++; return false; }
+    const int s = cs.n++;
+    // impedance, reference and regulariser: R = 2 mu^2 (1 - imp)/imp * (1 + mu^2) * (translational invweight0 of both bodies), mu = 1
+    T imp, K, B, tran;
+    if (kind == 0) { imp = impedance(tabs(dist)); K = T(so100g::SOLREF_K); B = T(so100g::SOLREF_B); tran = T(1.0/so100g::CUBE_MASS); }
+    else {
+        imp = impedance_pad(tabs(dist)); K = T(so100g::PADC_K); B = T(so100g::PADC_B);
+        tran = (kind == 1 || kind == 3) ? T(so100g::LINK_INVWEIGHT_TRAN[4]) : T(so100g::LINK_INVWEIGHT_TRAN[5]);
+        if (kind >= 3) tran += T(1.0/so100g::CUBE_MASS);
+    }
+    const T R = T(4)*tran*(T(1) - imp)*trcp(imp);
+    cs.set(s, C_PX, p[0]); cs.set(s, C_PY, p[1]); cs.set(s, C_PZ, p[2]);
+    cs.set(s, C_NX, n[0]); cs.set(s, C_NY, n[1]); cs.set(s, C_NZ, n[2]);
+    cs.set(s, C_KD, K*imp*dist); cs.set(s, C_RINV, trcp(R)); cs.set(s, C_KIND, T(kind));
+    cs.set(s, C_VX, B*vrel[0]); cs.set(s, C_VY, B*vrel[1]); cs.set(s, C_VZ, B*vrel[2]);
+    return true;
+}
+
+// the cube's point velocity / acceleration: x = (linear, world frame; angular, BODY frame) like MuJoCo's free-joint dofs
+template <typename T> SO100_HD void cube_point_motion(const T Rc[9], const T cpos[3], const T x[6], const T p[3], T out[3]) {
+    const T ww[3] = { Rc[0]*x[3] + Rc[1]*x[4] + Rc[2]*x[5], Rc[3]*x[3] + Rc[4]*x[4] + Rc[5]*x[5], Rc[6]*x[3] + Rc[7]*x[4] + Rc[8]*x[5] };
+    const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
+    T t[3]; cross(ww, r, t);
+    out[0] = x[0] + t[0]; out[1] = x[1] + t[1]; out[2] = x[2] + t[2];
+}
+
+// ---- narrowphase -----------------------------------------------------------------------------------------------------------
+// mjc_PlaneBox against the floor z = 0: corners at / below the plane and below the box centre, in corner order, at most 4.
+// R row-major, world <- box.  `emit(p, dist)` is called per contact.
+template <typename T, class Emit>
+SO100_HD void plane_box(const T c[3], const T R[9], const T h[3], Emit emit) {
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const T v0 = (k & 1) ? h[0] : -h[0], v1 = (k & 2) ? h[1] : -h[1], v2 = (k & 4) ? h[2] : -h[2];
+        const T lz = R[6]*v0 + R[7]*v1 + R[8]*v2;
+        if (!(c[2] + lz > T(0) || lz > T(0)) && cnt < 4) {
+            const T dist = c[2] + lz;
+            const T p[3] = { R[0]*v0 + R[1]*v1 + R[2]*v2 + c[0], R[3]*v0 + R[4]*v1 + R[5]*v2 + c[1], lz + c[2] - T(0.5)*dist };
+            emit(p, dist);
+            cnt++;
+        }
+    }
+}
+
+// Box-box (see oracle/so100_oracle.c: so100o_box_box for the algorithm; this is the same sequence of operations).
+// Boxes: centre, rotation (row-major, world <- box: COLUMNS are the box axes), half sizes.  Normal from A to B.
+// `emit(p, dist)` per contact, at most 8; returns the normal in nrm.
+template <typename T, class Emit>
+SO100_HD int box_box(const T cA[3], const T RA[9], const T hA[3], const T cB[3], const T RB[9], const T hB[3], T nrm[3], Emit emit) {
+    T a[3][3], b[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) { a[i][k] = RA[3*k + i]; b[i][k] = RB[3*k + i]; }
+    const T dd[3] = { cB[0] - cA[0], cB[1] - cA[1], cB[2] - cA[2] };
+    T Rm[3][3], Ra[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) { Rm[i][j] = dot(a[i], b[j]); Ra[i][j] = tabs(Rm[i][j]); }
+    T best = T(-1e30), bn[3] = { T(0), T(0), T(0) }; int code = -1;
+    bool sep_found = false;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const T proj = dot(dd, a[i]);
+        const T sep = tabs(proj) - (hA[i] + hB[0]*Ra[i][0] + hB[1]*Ra[i][1] + hB[2]*Ra[i][2]);
+        sep_found = sep_found || sep > T(0);
+        if (sep > best) { best = sep; code = i; const T sg = proj < T(0) ? T(-1) : T(1); bn[0] = sg*a[i][0]; bn[1] = sg*a[i][1]; bn[2] = sg*a[i][2]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const T proj = dot(dd, b[j]);
+        const T sep = tabs(proj) - (hB[j] + hA[0]*Ra[0][j] + hA[1]*Ra[1][j] + hA[2]*Ra[2][j]);
+        sep_found = sep_found || sep > T(0);
+        if (sep > best) { best = sep; code = 3 + j; const T sg = proj < T(0) ? T(-1) : T(1); bn[0] = sg*b[j][0]; bn[1] = sg*b[j][1]; bn[2] = sg*b[j][2]; }
+    }
+    T ebest = T(-1e30), en[3] = { T(0), T(0), T(0) }; int ecode = -1;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            T L[3]; cross(a[i], b[j], L);
+            const T len = tsqrt(dot(L, L));
+            if (len >= T(1e-6)) {
+                const T rl = trcp(len);
+                L[0] *= rl; L[1] *= rl; L[2] *= rl;
+                const T proj = dot(dd, L);
+                T ra = T(0), rb = T(0);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { ra += hA[k]*tabs(dot(a[k], L)); rb += hB[k]*tabs(dot(b[k], L)); }
+                const T sep = tabs(proj) - (ra + rb);
+                sep_found = sep_found || sep > T(0);
+                if (sep > ebest) { ebest = sep; ecode = 6 + 3*i + j; const T sg = proj < T(0) ? T(-1) : T(1); en[0] = sg*L[0]; en[1] = sg*L[1]; en[2] = sg*L[2]; }
+            }
+        }
+    if (sep_found) return 0;
+    if (ecode >= 0 && ebest*T(1.05) > best + T(1e-9)) { best = ebest; code = ecode; bn[0] = en[0]; bn[1] = en[1]; bn[2] = en[2]; }
+    nrm[0] = bn[0]; nrm[1] = bn[1]; nrm[2] = bn[2];
+
+    if (code >= 6) {
+        // edge-edge: supporting edge of A towards +n, of B towards -n; closest points of the two lines, clamped to the edges
+        const int i = (code - 6) / 3, j = (code - 6) % 3;
+        T pa[3] = { cA[0], cA[1], cA[2] }, pb[3] = { cB[0], cB[1], cB[2] };
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q != i) { const T sg = dot(bn, a[q]) > T(0) ? T(1) : T(-1); pa[0] += sg*hA[q]*a[q][0]; pa[1] += sg*hA[q]*a[q][1]; pa[2] += sg*hA[q]*a[q][2]; }
+            if (q != j) { const T sg = dot(bn, b[q]) > T(0) ? T(-1) : T(1); pb[0] += sg*hB[q]*b[q][0]; pb[1] += sg*hB[q]*b[q][1]; pb[2] += sg*hB[q]*b[q][2]; }
+        }
+        T ai[3], bj[3], hAi = T(0), hBj = T(0), uu = T(0);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            if (q == i) { ai[0] = a[q][0]; ai[1] = a[q][1]; ai[2] = a[q][2]; hAi = hA[q]; }
+            if (q == j) { bj[0] = b[q][0]; bj[1] = b[q][1]; bj[2] = b[q][2]; hBj = hB[q]; }
+        }
+        uu = dot(ai, bj);
+        const T w0[3] = { pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2] };
+        const T d1 = dot(ai, w0), d2 = dot(bj, w0), den = T(1) - uu*uu;
+        T sa = T(0), tb = T(0);
+        if (den > T(1e-12)) { const T rd = trcp(den); sa = (d1 - uu*d2)*rd; tb = (uu*d1 - d2)*rd; }
+        sa = tclamp(sa, -hAi, hAi); tb = tclamp(tb, -hBj, hBj);
+        const T p[3] = { T(0.5)*((pa[0] + sa*ai[0]) + (pb[0] + tb*bj[0])), T(0.5)*((pa[1] + sa*ai[1]) + (pb[1] + tb*bj[1])),
+                         T(0.5)*((pa[2] + sa*ai[2]) + (pb[2] + tb*bj[2])) };
+        emit(p, best);
+        return 1;
+    }
+
+    // face contact: X = reference box (owner of the axis), Y = incident box
+    const bool refA = code < 3; const int r = refA ? code : code - 3;
+    T x[3][3], y[3][3], cX[3], cY[3], hX[3], hY[3], nref[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { x[i][k] = refA ? a[i][k] : b[i][k]; y[i][k] = refA ? b[i][k] : a[i][k]; }
+        cX[i] = refA ? cA[i] : cB[i]; cY[i] = refA ? cB[i] : cA[i]; hX[i] = refA ? hA[i] : hB[i]; hY[i] = refA ? hB[i] : hA[i];
+        nref[i] = refA ? bn[i] : -bn[i];
+    }
+    int mi = 0; T mv = T(-1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const T v = tabs(dot(nref, y[k])); if (v > mv) { mv = v; mi = k; } }
+    // select the axes by index without dynamic register indexing
+    T ym[3], yp1[3], yp2[3], xr[3], xu1[3], xu2[3], hYm = T(0), hYp1 = T(0), hYp2 = T(0), hXr = T(0), hu = T(0), hv = T(0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k == mi) { ym[0] = y[k][0]; ym[1] = y[k][1]; ym[2] = y[k][2]; hYm = hY[k]; }
+        if (k == (mi + 1) % 3) { yp1[0] = y[k][0]; yp1[1] = y[k][1]; yp1[2] = y[k][2]; hYp1 = hY[k]; }
+        if (k == (mi + 2) % 3) { yp2[0] = y[k][0]; yp2[1] = y[k][1]; yp2[2] = y[k][2]; hYp2 = hY[k]; }
+        if (k == r) { xr[0] = x[k][0]; xr[1] = x[k][1]; xr[2] = x[k][2]; hXr = hX[k]; }
+        if (k == (r + 1) % 3) { xu1[0] = x[k][0]; xu1[1] = x[k][1]; xu1[2] = x[k][2]; hu = hX[k]; }
+        if (k == (r + 2) % 3) { xu2[0] = x[k][0]; xu2[1] = x[k][1]; xu2[2] = x[k][2]; hv = hX[k]; }
+    }
+    (void)xr;
+    const T fs = dot(nref, ym) > T(0) ? T(-1) : T(1);
+    T fc[3], rc[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rc[k] = cX[k] + hXr*nref[k]; fc[k] = cY[k] + fs*hYm*ym[k] - rc[k]; }
+    // incident face in reference-face coordinates (u, v, height w): centre c0 + alpha e1 + beta e2
+    const T c0[3] = { dot(fc, xu1), dot(fc, xu2), dot(fc, nref) };
+    const T e1[3] = { hYp1*dot(yp1, xu1), hYp1*dot(yp1, xu2), hYp1*dot(yp1, nref) };
+    const T e2[3] = { hYp2*dot(yp2, xu1), hYp2*dot(yp2, xu2), hYp2*dot(yp2, nref) };
+    int cnt = 0;
+    auto out = [&](T u, T v, T w) {
+        if (w <= T(0) && cnt < 8) {
+            const T p[3] = { rc[0] + u*xu1[0] + v*xu2[0] + T(0.5)*w*nref[0], rc[1] + u*xu1[1] + v*xu2[1] + T(0.5)*w*nref[1],
+                             rc[2] + u*xu1[2] + v*xu2[2] + T(0.5)*w*nref[2] };
+            emit(p, w);
+            cnt++;
+        }
+    };
+    // slots 0-7: per incident edge its Liang-Barsky entry point (or start vertex) and, when it leaves the rectangle early, its exit point
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const T sa0 = (k == 0 || k == 3) ? T(-1) : T(1), sb0 = (k < 2) ? T(-1) : T(1);
+        const int k2 = (k + 1) & 3;
+        const T sa1 = (k2 == 0 || k2 == 3) ? T(-1) : T(1), sb1 = (k2 < 2) ? T(-1) : T(1);
+        const T P0[3] = { c0[0] + sa0*e1[0] + sb0*e2[0], c0[1] + sa0*e1[1] + sb0*e2[1], c0[2] + sa0*e1[2] + sb0*e2[2] };
+        const T P1[3] = { c0[0] + sa1*e1[0] + sb1*e2[0], c0[1] + sa1*e1[1] + sb1*e2[1], c0[2] + sa1*e1[2] + sb1*e2[2] };
+        T t0 = T(0), t1 = T(1); bool ok = true;
+#pragma unroll
+        for (int ax = 0; ax < 2; ax++) {
+            const T dq = P1[ax] - P0[ax], lim = ax == 0 ? hu : hv;
+#pragma unroll
+            for (int side = -1; side <= 1; side += 2) {
+                const T pden = -T(side)*dq, pnum = T(side)*P0[ax] - lim;
+                if (pden == T(0)) { if (pnum > T(0)) ok = false; }
+                else {
+                    const T t = pnum/pden;
+                    if (pden > T(0)) { if (t > t0) t0 = t; } else { if (t < t1) t1 = t; }
+                }
+            }
+        }
+        if (t0 > t1) ok = false;
+        if (ok) out(P0[0] + t0*(P1[0] - P0[0]), P0[1] + t0*(P1[1] - P0[1]), P0[2] + t0*(P1[2] - P0[2]));
+        if (ok && t1 < T(1)) out(P0[0] + t1*(P1[0] - P0[0]), P0[1] + t1*(P1[1] - P0[1]), P0[2] + t1*(P1[2] - P0[2]));
+    }
+    {   // slots 8-11: rectangle corners inside the incident parallelogram
+        const T det = e1[0]*e2[1] - e1[1]*e2[0];
+        if (tabs(det) > T(1e-18)) {
+            const T rd = T(1)/det;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const T su = (k == 0 || k == 3) ? T(-1) : T(1), sv = (k < 2) ? T(-1) : T(1);
+                const T uu = su*hu - c0[0], vv = sv*hv - c0[1];
+                const T al = (uu*e2[1] - vv*e2[0])*rd, be = (e1[0]*vv - e1[1]*uu)*rd;
+                if (tabs(al) < T(1) && tabs(be) < T(1)) out(su*hu, sv*hv, c0[2] + al*e1[2] + be*e2[2]);
+            }
+        }
+    }
+    return cnt;
+}
+
+// ---- detection: fills the contact store for one env --------------------------------------------------------------------
+// v = q-dot of the arm, cube pose / velocity; W = world FK of this substep.  Store order: pad/floor by pad, pad/cube by pad
+// (these two share the budget MAXPADC), then -- only when a pad touches the cube, i.e. arm and cube must be solved together --
+// the cube's own floor contacts (otherwise the cube keeps its separate Newton solve in so100_cube.hpp).
+// Returns true when at least one pad/cube contact exists.
+template <typename T, class Store>
+SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<T>& cube, const T Rc[9], unsigned flags, bool cube_live, Store& cs) {
+    cs.n = 0; cs.dropped = 0;
+    Spatial<T> V4, V5;
+    link_spatial(W, v, V4, V5);
+    const T nz[3] = { T(0), T(0), T(1) };
+    const T hc[3] = { T(so100g::CUBE_HALF), T(so100g::CUBE_HALF), T(so100g::CUBE_HALF) };
+    bool coupled = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {                   // pass 0: pad/floor, pass 1: pad/cube
+        if (pass == 0 && (flags & F_PADS_FLOOR) == 0u) continue;
+        if (pass == 1 && ((flags & F_PADS_CUBE) == 0u || !cube_live)) continue;
+#pragma unroll 1
+        for (int g = 0; g < so100g::NPAD; g++) {
+            const bool l5 = so100g::PAD_LINK[g] == 5;
+            const T* R = l5 ? W.R5 : W.R4; const T* o = l5 ? W.o[5] : W.o[4];
+            const T pp[3] = { T(so100g::PAD_POS[g][0]), T(so100g::PAD_POS[g][1]), T(so100g::PAD_POS[g][2]) };
+            const T h[3] = { T(so100g::PAD_SIZE[g][0]), T(so100g::PAD_SIZE[g][1]), T(so100g::PAD_SIZE[g][2]) };
+            const T c[3] = { o[0] + R[0]*pp[0] + R[1]*pp[1] + R[2]*pp[2], o[1] + R[3]*pp[0] + R[4]*pp[1] + R[5]*pp[2], o[2] + R[6]*pp[0] + R[7]*pp[1] + R[8]*pp[2] };
+            if (pass == 0) {
+                if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) {
+                    plane_box<T>(c, R, h, [&](const T* p, T dist) {
+                        T vr[3]; point_motion(l5 ? V5 : V4, p, vr);
+                        contact_add(cs, l5 ? 2 : 1, p, nz, dist, vr);
+                    });
+                }
+            } else {
+                const T dx = c[0] - cube.pos[0], dy = c[1] - cube.pos[1], dz = c[2] - cube.pos[2];
+                const T rr = tsqrt(h[0]*h[0] + h[1]*h[1] + h[2]*h[2]) + T(so100g::CUBE_HALF*1.7320508075688772);
+                if (dx*dx + dy*dy + dz*dz < rr*rr) {          // bounding spheres overlap: run the separating-axis test
+                    // the points are emitted before the normal is returned: records are appended with a placeholder, then patched
+                    const int s0 = cs.n;
+                    T nrm[3];
+                    const int k = box_box<T>(c, R, h, cube.pos, Rc, hc, nrm, [&](const T* p, T dist) {
+                        T va[3], vc[3]; point_motion(l5 ? V5 : V4, p, va); cube_point_motion(Rc, cube.pos, cube.vel, p, vc);
+                        const T vr[3] = { vc[0] - va[0], vc[1] - va[1], vc[2] - va[2] };
+                        contact_add(cs, l5 ? 4 : 3, p, nz, dist, vr);
+                    });
+                    coupled = coupled || k > 0;
+                    for (int s = s0; s < cs.n; s++) { cs.set(s, C_NX, nrm[0]); cs.set(s, C_NY, nrm[1]); cs.set(s, C_NZ, nrm[2]); }
+                }
+            }
+        }
+    }
+    if (coupled && (flags & F_FLOOR) != 0u) {
+        plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist) {
+            T vr[3]; cube_point_motion(Rc, cube.pos, cube.vel, p, vr);
+            contact_add(cs, 0, p, nz, dist, vr);
+        });
+    }
+    return coupled;
+}
+
+// ---- N x N SPD systems, N = 6 or 12: LDL^T in place on the packed lower triangle -----------------------------------------
+template <int N, typename T> SO100_HD void ldln(T M[N*(N+1)/2], T Dinv[N]) {
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        T d = M[SO100_TRI(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= M[SO100_TRI(j, k)]*M[SO100_TRI(j, k)]*M[SO100_TRI(k, k)];
+        M[SO100_TRI(j, j)] = d;
+        Dinv[j] = trcp(d);
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            T t = M[SO100_TRI(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= M[SO100_TRI(i, k)]*M[SO100_TRI(j, k)]*M[SO100_TRI(k, k)];
+            M[SO100_TRI(i, j)] = t*Dinv[j];
+        }
+    }
+}
+template <int N, typename T> SO100_HD void ldln_solve(const T L[N*(N+1)/2], const T Dinv[N], T x[N]) {
+#pragma unroll
+    for (int i = 1; i < N; i++)
+#pragma unroll
+        for (int k = 0; k < i; k++) x[i] -= L[SO100_TRI(i, k)]*x[k];
+#pragma unroll
+    for (int i = 0; i < N; i++) x[i] *= Dinv[i];
+#pragma unroll
+    for (int i = N - 2; i >= 0; i--)
+#pragma unroll
+        for (int k = i + 1; k < N; k++) x[i] -= L[SO100_TRI(k, i)]*x[k];
+}
+// M (packed lower) from its LDL^T factor (arm_factor leaves only the factor in A.M)
+template <typename T> SO100_HD void ldl6_reconstruct(const T L[21], T M[21]) {
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            T t = T(0);
+#pragma unroll
+            for (int k = 0; k <= j; k++) {
+                const T lik = k == i ? T(1) : L[SO100_TRI(i, k)], ljk = k == j ? T(1) : L[SO100_TRI(j, k)];
+                t += lik*ljk*L[SO100_TRI(k, k)];
+            }
+            M[SO100_TRI(i, j)] = t;
+        }
+}
+
+// ---- the primal problem of one env's substep ----------------------------------------------------------------------------
+// ND = 6: arm only (pad/floor contacts);  ND = 12: arm + cube (a pad touches the cube): x = [arm qacc (6) ; cube qacc (6)]
+template <int ND, typename T, class Store> struct PrimalProblem {
+    const WorldFK<T>& W; const Store& cs;
+    const T* Marm;             // packed lower 6x6
+    const T* tau;              // arm smooth force
+    const ArmRows<T>& rows;    // friction / limit row constants
+    const T* Rc; const T* cpos; const T* a0c;      // cube rotation (world <- body), centre, smooth linear acceleration (ND = 12)
+    static constexpr int NH = ND*(ND + 1)/2;
+
+    // cost at x; MODE 0: cost only, 1: + gradient, 2: + Hessian
+    template <int MODE> SO100_HD T eval(const T x[ND], T g[ND], T H[NH]) const {
+        T cost = T(0);
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < NH; i++) H[i] = T(0);
+#pragma unroll
+            for (int i = 0; i < 21; i++) H[i] = Marm[i];
+        }
+        // smooth part, arm: 1/2 x'Mx - x'tau
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T t = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
+            cost += x[i]*(T(0.5)*t - tau[i]);
+            if (MODE >= 1) g[i] = t - tau[i];
+        }
+        if (ND == 12) {
+            const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const T dl = x[6 + i] - a0c[i], da = x[9 + i];
+                cost += T(0.5)*(m*dl*dl + I*da*da);
+                if (MODE >= 1) { g[6 + i] = m*dl; g[9 + i] = I*da; }
+                if (MODE == 2) { H[SO100_TRI(6 + i, 6 + i)] = m; H[SO100_TRI(9 + i, 9 + i)] = I; }
+            }
+        }
+        // friction-loss rows (Huber) and limit rows (one-sided) of the arm: J = +-e_i
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const T F = rows.fmax_[i];
+            if (F > T(0)) {
+                const T R = rows.Rf[i], D = trcp(R), jar = x[i] + rows.cfv[i];
+                if (jar <= -R*F)     { cost += -T(0.5)*R*F*F - F*jar; if (MODE >= 1) g[i] -= F; }
+                else if (jar >= R*F) { cost += -T(0.5)*R*F*F + F*jar; if (MODE >= 1) g[i] += F; }
+                else { cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D; }
+            }
+            const T sg = rows.sg[i];
+            if (sg != T(0)) {
+                const T jar = sg*x[i] + rows.clv[i];
+                if (jar < T(0)) {
+                    const T D = trcp(rows.Rl[i]);
+                    cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += sg*D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D;
+                }
+            }
+        }
+        // contacts
+        Spatial<T> S4, S5;
+        link_spatial(W, x, S4, S5);
+        T F4[3] = { T(0), T(0), T(0) }, T4[3] = { T(0), T(0), T(0) }, F5[3] = { T(0), T(0), T(0) }, T5[3] = { T(0), T(0), T(0) };
+#pragma unroll 1
+        for (int s = 0; s < cs.n; s++) {
+            const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
+            const T n[3] = { cs.get(s, C_NX), cs.get(s, C_NY), cs.get(s, C_NZ) };
+            T t1[3], t2[3]; contact_frame(n, t1, t2);
+            const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
+            const int kind = (int)cs.get(s, C_KIND);
+            const bool on5 = kind == 2 || kind == 4, arm_side = kind != 0, cube_side = kind == 0 || kind >= 3;
+            const T sgn = kind >= 3 ? T(-1) : T(1);             // the arm link is geom1 in pad/cube pairs, geom2 in pad/floor pairs
+            T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) };
+            if (arm_side) { T ap[3]; point_motion(on5 ? S5 : S4, p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
+            if (ND == 12 && cube_side) { T ac[3]; cube_point_motion(Rc, cpos, x + 6, p, ac); w[0] += ac[0]; w[1] += ac[1]; w[2] += ac[2]; }
+            const T jn = dot(n, w) + kd, j1 = dot(t1, w), j2 = dot(t2, w);
+            const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 };        // edges n +- mu t1, n +- mu t2 (mu = 1)
+            T m_[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) { m_[e] = jar[e] < T(0) ? jar[e] : T(0); cost += T(0.5)*D*m_[e]*m_[e]; }
+            if (MODE >= 1) {
+                const T cn = D*(m_[0] + m_[1] + m_[2] + m_[3]), c1 = D*(m_[0] - m_[1]), c2 = D*(m_[2] - m_[3]);
+                const T Fv[3] = { cn*n[0] + c1*t1[0] + c2*t2[0], cn*n[1] + c1*t1[1] + c2*t2[1], cn*n[2] + c1*t1[2] + c2*t2[2] };
+                if (arm_side) {
+                    T tq[3]; cross(p, Fv, tq);
+                    if (on5) { F5[0] += sgn*Fv[0]; F5[1] += sgn*Fv[1]; F5[2] += sgn*Fv[2]; T5[0] += sgn*tq[0]; T5[1] += sgn*tq[1]; T5[2] += sgn*tq[2]; }
+                    else     { F4[0] += sgn*Fv[0]; F4[1] += sgn*Fv[1]; F4[2] += sgn*Fv[2]; T4[0] += sgn*tq[0]; T4[1] += sgn*tq[1]; T4[2] += sgn*tq[2]; }
+                }
+                if (ND == 12 && cube_side) {
+                    const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
+                    T tw[3]; cross(r, Fv, tw);
+                    g[6] += Fv[0]; g[7] += Fv[1]; g[8] += Fv[2];
+                    g[9]  += Rc[0]*tw[0] + Rc[3]*tw[1] + Rc[6]*tw[2];
+                    g[10] += Rc[1]*tw[0] + Rc[4]*tw[1] + Rc[7]*tw[2];
+                    g[11] += Rc[2]*tw[0] + Rc[5]*tw[1] + Rc[8]*tw[2];
+                }
+            }
+            if (MODE == 2) {
+                // explicit rows of the active edges: J_e = [sgn d_e . (z_i x (p - o_i)), i <= link ; d_e ; Rc'((p - c) x d_e)]
+                T cn_[ND], c1_[ND], c2_[ND];                    // the point Jacobian's columns projected on n, t1, t2
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    const bool moves = arm_side && (i < 5 || on5);
+                    const T r[3] = { p[0] - W.o[i][0], p[1] - W.o[i][1], p[2] - W.o[i][2] };
+                    T col[3]; cross(W.z[i], r, col);
+                    cn_[i] = moves ? sgn*dot(n, col) : T(0); c1_[i] = moves ? sgn*dot(t1, col) : T(0); c2_[i] = moves ? sgn*dot(t2, col) : T(0);
+                }
+                if (ND == 12) {
+                    const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
+                    const T on = cube_side ? T(1) : T(0);
+                    const T* dirs[3] = { n, t1, t2 }; T* outs[3] = { cn_, c1_, c2_ };
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        const T* d = dirs[a]; T* o = outs[a];
+                        T tw[3]; cross(r, d, tw);
+                        o[6] = on*d[0]; o[7] = on*d[1]; o[8] = on*d[2];
+                        o[9]  = on*(Rc[0]*tw[0] + Rc[3]*tw[1] + Rc[6]*tw[2]);
+                        o[10] = on*(Rc[1]*tw[0] + Rc[4]*tw[1] + Rc[7]*tw[2]);
+                        o[11] = on*(Rc[2]*tw[0] + Rc[5]*tw[1] + Rc[8]*tw[2]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const T De = jar[e] < T(0) ? D : T(0);
+                    T J[ND];
+#pragma unroll
+                    for (int i = 0; i < ND; i++) J[i] = cn_[i] + (e == 0 ? c1_[i] : e == 1 ? -c1_[i] : e == 2 ? c2_[i] : -c2_[i]);
+#pragma unroll
+                    for (int i = 0; i < ND; i++) {
+                        const T dj = De*J[i];
+#pragma unroll
+                        for (int j = 0; j <= i; j++) H[SO100_TRI(i, j)] += dj*J[j];
+                    }
+                }
+            }
+        }
+        if (MODE >= 1) {
+            // contact wrenches -> joint space: g_i += z_i . (T - o_i x F), links >= i
+            const T F45[3] = { F4[0] + F5[0], F4[1] + F5[1], F4[2] + F5[2] }, T45[3] = { T4[0] + T5[0], T4[1] + T5[1], T4[2] + T5[2] };
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;
+                T oxf[3]; cross(W.o[i], Fa, oxf);
+                g[i] += W.z[i][0]*(Ta[0] - oxf[0]) + W.z[i][1]*(Ta[1] - oxf[1]) + W.z[i][2]*(Ta[2] - oxf[2]);
+            }
+        }
+        return cost;
+    }
+
+    // derivatives of phi(alpha) = cost(x + alpha dx) at alpha: d1 = phi', d2 = phi'' (of the current active set).  phi' is
+    // continuous, increasing and piecewise linear, so Newton on it is exact within one piece.
+    SO100_HD void line_deriv(const T x[ND], const T dx[ND], T alpha, T& d1, T& d2) const {
+        T xa[ND];
+#pragma unroll
+        for (int i = 0; i < ND; i++) xa[i] = x[i] + alpha*dx[i];
+        d1 = T(0); d2 = T(0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T t = T(0), u = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) { t += sym6(Marm, i, j)*xa[j]; u += sym6(Marm, i, j)*dx[j]; }
+            d1 += dx[i]*(t - tau[i]); d2 += dx[i]*u;
+        }
+        if (ND == 12) {
+            const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                d1 += m*(xa[6 + i] - a0c[i])*dx[6 + i] + I*xa[9 + i]*dx[9 + i];
+                d2 += m*dx[6 + i]*dx[6 + i] + I*dx[9 + i]*dx[9 + i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const T F = rows.fmax_[i];
+            if (F > T(0)) {
+                const T R = rows.Rf[i], D = trcp(R), jar = xa[i] + rows.cfv[i];
+                if (jar <= -R*F) d1 -= F*dx[i];
+                else if (jar >= R*F) d1 += F*dx[i];
+                else { d1 += D*jar*dx[i]; d2 += D*dx[i]*dx[i]; }
+            }
+            const T sg = rows.sg[i];
+            if (sg != T(0)) {
+                const T jar = sg*xa[i] + rows.clv[i];
+                if (jar < T(0)) { const T D = trcp(rows.Rl[i]); d1 += D*jar*sg*dx[i]; d2 += D*dx[i]*dx[i]; }
+            }
+        }
+        Spatial<T> S4, S5, D4, D5;
+        link_spatial(W, xa, S4, S5);
+        link_spatial(W, dx, D4, D5);
+#pragma unroll 1
+        for (int s = 0; s < cs.n; s++) {
+            const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
+            const T n[3] = { cs.get(s, C_NX), cs.get(s, C_NY), cs.get(s, C_NZ) };
+            T t1[3], t2[3]; contact_frame(n, t1, t2);
+            const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
+            const int kind = (int)cs.get(s, C_KIND);
+            const bool on5 = kind == 2 || kind == 4, arm_side = kind != 0, cube_side = kind == 0 || kind >= 3;
+            const T sgn = kind >= 3 ? T(-1) : T(1);
+            T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) }, wd[3] = { T(0), T(0), T(0) };
+            if (arm_side) {
+                T ap[3], ad[3]; point_motion(on5 ? S5 : S4, p, ap); point_motion(on5 ? D5 : D4, p, ad);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { w[k] += sgn*ap[k]; wd[k] += sgn*ad[k]; }
+            }
+            if (ND == 12 && cube_side) {
+                T ac[3], ad[3]; cube_point_motion(Rc, cpos, xa + 6, p, ac); cube_point_motion(Rc, cpos, dx + 6, p, ad);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { w[k] += ac[k]; wd[k] += ad[k]; }
+            }
+            const T jn = dot(n, w) + kd, j1 = dot(t1, w), j2 = dot(t2, w), dn = dot(n, wd), e1 = dot(t1, wd), e2 = dot(t2, wd);
+            const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 }, jd[4] = { dn + e1, dn - e1, dn + e2, dn - e2 };
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (jar[e] < T(0)) { d1 += D*jar[e]*jd[e]; d2 += D*jd[e]*jd[e]; }
+        }
+    }
+};
+
+#if !defined(__HIPCC__)
+static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0;     // host-only instrumentation
+static int g_dbg_cnewton_trace = 0;
+#endif
+
+// Newton on the primal problem.  x: warm start in, solution out.  L6 / Dinv6: LDL^T factor of the arm's M (for the cheap
+// optimality test g'M^-1 g).  Returns the size of the last step (the solver residual a caller can watch).
+template <int ND, typename T, class Store>
+SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, const T* L6, const T* Dinv6, int iters, T x[ND]) {
+    constexpr int NH = ND*(ND + 1)/2;
+    const bool f32 = sizeof(T) == 4;
+    T last = T(0);
+#if !defined(__HIPCC__)
+    g_dbg_cnewton_calls++;
+#endif
+    for (int it = 0; it < iters; it++) {
+        T g[ND], H[NH], Dinv[ND], dx[ND];
+        // cheap optimality test from the gradient alone: H >= M, so dx'M dx <= g'M^-1 g =: E bounds the Newton step
+        {
+            P.template eval<1>(x, g, H);
+            T t[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) t[i] = g[i];
+            ldl6_solve(L6, Dinv6, t);
+            T E = T(0), xm = T(0);
+#pragma unroll
+            for (int i = 0; i < 6; i++) { E += g[i]*t[i]; xm = tmax(xm, tabs(x[i])); }
+            // arm: M >= armature (0.1) => |dx|^2 <= E / 0.1
+            const T tol = (f32 ? T(0.25e-4) : T(0.25e-11))*(T(1) + T(0.01)*xm);
+            bool small = E < T(so100g::ARMATURE)*tol*tol;
+            if (ND == 12) {
+                const T Ec = (g[6]*g[6] + g[7]*g[7] + g[8]*g[8])*T(1.0/so100g::CUBE_MASS) + (g[9]*g[9] + g[10]*g[10] + g[11]*g[11])*T(1.0/so100g::CUBE_INERTIA);
+                const T tq = f32 ? T(0.25e-4) : T(0.25e-11);
+                small = small && Ec < tq*tq*T(so100g::CUBE_MASS/1.5);
+            }
+            if (small) { last = T(0); break; }
+        }
+#if !defined(__HIPCC__)
+        g_dbg_cnewton_iters++;
+#endif
+        P.template eval<2>(x, g, H);
+#pragma unroll
+        for (int i = 0; i < ND; i++) dx[i] = -g[i];
+        ldln<ND>(H, Dinv);
+        ldln_solve<ND>(H, Dinv, dx);
+        T dmax = T(0), xmax = T(0);
+#pragma unroll
+        for (int i = 0; i < ND; i++) {
+            const T sc = (ND == 12 && i >= 9) ? T(so100g::CUBE_HALF) : T(1);      // cube angular acceleration measured at the cube's corner
+            dmax = tmax(dmax, tabs(dx[i])*sc); xmax = tmax(xmax, tabs(x[i])*sc);
+        }
+        last = dmax;
+#if !defined(__HIPCC__)
+        if (g_dbg_cnewton_trace) printf("  it %d |g| %.3e dmax %.3e xmax %.3e\n", it, (double)tsqrt(g[0]*g[0]+g[1]*g[1]+g[2]*g[2]+g[3]*g[3]+g[4]*g[4]+g[5]*g[5]), (double)dmax, (double)xmax);
+#endif
+        const T tol = (f32 ? T(1e-4) : T(1e-11))*(T(1) + T(0.01)*xmax);
+        if (dmax < tol) {
+#pragma unroll
+            for (int i = 0; i < ND; i++) x[i] += dx[i];
+            break;
+        }
+        // Line search on phi(alpha) = cost(x + alpha dx) by safeguarded Newton on phi' (continuous, increasing, piecewise linear),
+        // starting with the full step.  No cost values are compared: 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost
+        // DIFFERENCE of the size of the predicted decrease is below the round-off of the two costs.  The outer loop never stops on
+        // the strength of the line search (phi'(1) small against phi'(0) = g.dx says little when g was 1e4 at a contact onset):
+        // only the gradient test at the top of the next iteration, or a step below tolerance, ends it.
+        T gdx = T(0);
+#pragma unroll
+        for (int i = 0; i < ND; i++) gdx += g[i]*dx[i];
+        T lo = T(0), hi = T(-1), alpha = T(1), d1, d2;          // hi < 0: no upper bracket yet
+#pragma unroll 1
+        for (int ls = 0; ls < 12; ls++) {
+            P.line_deriv(x, dx, alpha, d1, d2);
+#if !defined(__HIPCC__)
+            g_dbg_cnewton_ls++;
+#endif
+            if (tabs(d1) <= (f32 ? T(1e-4) : T(1e-10))*tabs(gdx)) break;
+            if (d1 < T(0)) lo = alpha; else hi = alpha;
+            T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
+            const bool inside = an > lo && (hi < T(0) || an < hi);
+            if (!inside) an = hi < T(0) ? T(2)*alpha : T(0.5)*(lo + hi);
+            if (tabs(an - alpha) <= (f32 ? T(1e-4) : T(1e-10))*tabs(alpha)) { alpha = an; break; }
+            alpha = an;
+        }
+#if !defined(__HIPCC__)
+        if (g_dbg_cnewton_trace) printf("     line search alpha %.6g\n", (double)alpha);
+#endif
+#pragma unroll
+        for (int i = 0; i < ND; i++) x[i] += alpha*dx[i];
+    }
+    return last;
+}
+
+// ---- one arm (+ cube) substep with pad contacts, single lane ----------------------------------------------------------
+// Called INSTEAD of arm_solve_integrate (+ cube_finish) by lanes that have pad contacts.  A holds the factorised mass matrix
+// (arm_factor) and the bias force.  aw: the arm's qacc warm start (previous substep's acceleration), updated.
+// coupled: solve the cube together with the arm (cs then holds its floor contacts too) and integrate it here.
+template <typename T, class Store>
+SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], unsigned flags, int iters,
+                                      Arm<T>& A, const WorldFK<T>& W, const Store& cs, bool coupled, Cube<T>& cube, const T Rc[9],
+                                      const T applied[3], T dq[6], T* residual) {
+    T tau[6], acc[6];
+    arm_tau(q, v, ctrl, A, tau);
+    ArmRows<T> r;
+    arm_rows(q, v, tau, ff, fl, flags, A, r);
+    T Marm[21];
+    ldl6_reconstruct(A.M, Marm);
+    T res;
+    const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
+    if (!coupled) {
+        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cube.pos, a0c };
+        T x[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = aw[i];
+        res = primal_newton<6>(P, A.M, A.Dinv, iters, x);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = x[i];
+    } else {
+        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cube.pos, a0c };
+        T x[12];
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = aw[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { x[6 + i] = cube.warm[i] + a0c[i]; x[9 + i] = cube.warm[3 + i]; }
+        res = primal_newton<12>(P, A.M, A.Dinv, iters, x);
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = x[i];
+        // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
+#pragma unroll
+        for (int i = 0; i < 3; i++) { cube.warm[i] = x[6 + i] - a0c[i]; cube.warm[3 + i] = x[9 + i]; }
+        const T al[3] = { x[6], x[7], x[8] }, aa[3] = { x[9], x[10], x[11] };
+        cube_integrate(cube, al, aa);
+    }
+    if (residual) *residual = tmax(*residual, res);
+    // row forces of the solution -> the block PGS's warm-start memory (a lane may be back on that path next substep)
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const T F = r.fmax_[i], R = r.Rf[i], jar = acc[i] + r.cfv[i];
+        ff[i] = F > T(0) ? tclamp(-jar*trcp(R), -F, F) : T(0);
+        const T jl = r.sg[i]*acc[i] + r.clv[i];
+        fl[i] = (r.sg[i] != T(0) && jl < T(0)) ? -jl*trcp(r.Rl[i]) : T(0);
+        aw[i] = acc[i];
+    }
+    arm_integrate(q, v, qc, acc, dq);
+}
+
+// One whole substep of one env with the pad-contact flags on, single lane (the one-wave step kernel and the host tests; the
+// multi-wave kernels run the same stages spread over their waves).  stat (optional): [0] contacts, [1] coupled, [2] dropped.
+template <typename T>
+SO100_HD void substep_with_pads(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], Cube<T>& cube, const T applied[3],
+                                unsigned flags, int solver_iters, int contact_iters, Arm<T>& A, bool first, T dq[6], T* residual, int* stat = nullptr) {
+    if (first) arm_trig(q, A); else arm_trig_update(q, dq, A);
+    arm_bias(v, A);
+    arm_mass(A);
+    arm_factor(flags, A);
+    const bool cube_live = (flags & F_CUBE_PINNED) == 0u;
+    WorldFK<T> W;
+    world_fk(A.s, A.c, W);
+    T qn[4] = { cube.quat[0], cube.quat[1], cube.quat[2], cube.quat[3] };
+    quat_normalize(qn);
+    T Rc[9]; quat_to_mat(qn, Rc);
+    ContactsPriv<T> cs;
+    const bool coupled = detect_pad_contacts(W, v, cube, Rc, flags, cube_live, cs);
+    if (stat) { stat[0] = cs.n; stat[1] = coupled ? 1 : 0; stat[2] = cs.dropped; }
+    if (cs.n > 0) {
+        contact_solve_integrate(q, v, qc, ctrl, ff, fl, aw, flags, contact_iters, A, W, cs, coupled, cube, Rc, applied, dq, residual);
+        if (!coupled) cube_substep(cube, applied, flags, contact_iters);
+    } else {
+        arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, solver_iters, A, dq, residual, aw);
+        cube_substep(cube, applied, flags, contact_iters);
+    }
+}
+
+}  // namespace so100

@@ -212,11 +212,11 @@ SO100_HD void cube_prepare(const Cube<T>& c, const T applied[3], unsigned flags,
     }
 }
 
+// cube_finish = cube_solve (Newton on the floor rows -> linear / angular acceleration) + cube_integrate (semi-implicit Euler)
 template <typename T>
-SO100_HD void cube_finish(Cube<T>& c, unsigned flags, int iters, const CubePrep<T>& P) {
-    const T h = T(so100g::TIMESTEP);
+SO100_HD void cube_solve(Cube<T>& c, unsigned flags, int iters, const CubePrep<T>& P, T al[3], T aa[3]) {
     const T* a0 = P.a0;
-    T al[3] = { a0[0], a0[1], a0[2] }, aa[3] = { T(0), T(0), T(0) };
+    al[0] = a0[0]; al[1] = a0[1]; al[2] = a0[2]; aa[0] = T(0); aa[1] = T(0); aa[2] = T(0);
     if (flags & F_FLOOR) {
         const CubeRows<T>& r = P.r;
         // Newton on x = qacc - qacc_smooth, warm-started from the previous substep
@@ -310,6 +310,11 @@ SO100_HD void cube_finish(Cube<T>& c, unsigned flags, int iters, const CubePrep<
         al[0] += wl[0]; al[1] += wl[1]; al[2] += wl[2];
         aa[0] = wa[0]; aa[1] = wa[1]; aa[2] = wa[2];
     }
+}
+
+template <typename T>
+SO100_HD void cube_integrate(Cube<T>& c, const T al[3], const T aa[3]) {
+    const T h = T(so100g::TIMESTEP);
     // mj_Euler
 #pragma unroll
     for (int i = 0; i < 3; i++) { c.vel[i] += h*al[i]; c.vel[3+i] += h*aa[i]; }
@@ -331,6 +336,13 @@ SO100_HD void cube_finish(Cube<T>& c, unsigned flags, int iters, const CubePrep<
     }
 }
 
+
+template <typename T>
+SO100_HD void cube_finish(Cube<T>& c, unsigned flags, int iters, const CubePrep<T>& P) {
+    T al[3], aa[3];
+    cube_solve(c, flags, iters, P, al, aa);
+    cube_integrate(c, al, aa);
+}
 
 template <typename T>
 SO100_HD void cube_substep(Cube<T>& c, const T applied[3], unsigned flags, int iters) {

@@ -453,15 +453,22 @@ template <typename T>
 SO100_HD void arm_factor(unsigned flags, Arm<T>& A) {
     // needs only A.M: LDL^T in place (+ the explicit inverse when constraint rows are simulated)
     ldl6(A.M, A.Dinv);
-    if ((flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u) ldl6_inverse(A.M, A.Dinv, A.Minv);
+    if ((flags & (F_FRICTIONLOSS | F_LIMITS | 16u | 32u)) != 0u) ldl6_inverse(A.M, A.Dinv, A.Minv);      // 16 | 32: the pad-contact flags (so100_contact.hpp)
 }
 
+// The solve of one arm substep in separately callable stages (so100_contact.hpp puts a contact-aware Newton solve between
+// arm_rows and arm_integrate for the lanes that have finger-pad contacts):
+//   arm_tau       : mj_fwdActuation - bias                      arm_rows : friction-loss / limit rows + a0 = M^-1 tau
+//   arm_pgs       : block Gauss-Seidel over the joints -> acc   arm_integrate : semi-implicit Euler (Kahan-compensated)
+template <typename T> struct ArmRows {
+    T a0[6];                                   // qacc_smooth of the arm
+    T bf[6], Rf[6], bl[6], Rl[6], sg[6], fmax_[6];
+    T cfv[6], clv[6];                          // the rows' constants without the a0 term: -aref = B Jv (+ K imp dist)
+};
+
 template <typename T>
-SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6]) {
-    // (A.M / A.Dinv / A.Minv hold this substep's factorised mass matrix, A.bias its bias force)
-    const T* Dinv = A.Dinv; const T* Minv = A.Minv;
+SO100_HD void arm_tau(const T q[6], const T v[6], const T ctrl[6], const Arm<T>& A, T tau[6]) {
     // mj_fwdActuation: position servo kp (u - q) - kv qd, u clamped to ctrlrange, force to forcerange
-    T tau[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         const T u = tclamp(ctrl[i], T(-so100g::ACT_CTRL), T(so100g::ACT_CTRL));
@@ -469,89 +476,101 @@ SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff
         f = tclamp(f, T(-so100g::ACT_FORCE), T(so100g::ACT_FORCE));
         tau[i] = f - A.bias[i];
     }
-    T acc[6];
-    const bool constrained = (flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u;
-    if (!constrained) {
+}
+
+template <typename T>
+SO100_HD void arm_rows(const T q[6], const T v[6], const T tau[6], T ff[6], T fl[6], unsigned flags, const Arm<T>& A, ArmRows<T>& r) {
+    const T* Minv = A.Minv;
 #pragma unroll
-        for (int i = 0; i < 6; i++) acc[i] = tau[i];
-        ldl6_solve(A.M, Dinv, acc);
-    } else {
-        T a0[6];
+    for (int i = 0; i < 6; i++) {
+        T t = T(0);
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            T t = T(0);
+        for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tau[j];
+        r.a0[i] = t;
+    }
+    // rows: friction (J = e_i, |f| <= frictionloss) then limits (J = sg_i e_i, f >= 0)
+    const T Bd = T(so100g::SOLREF_B), Kd = T(so100g::SOLREF_K);
 #pragma unroll
-            for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tau[j];
-            a0[i] = t;
-        }
-        // rows: friction (J = e_i, |f| <= frictionloss) then limits (J = sg_i e_i, f >= 0)
-        const T Bd = T(so100g::SOLREF_B), Kd = T(so100g::SOLREF_K);
-        T bf[6], Rf[6], bl[6], Rl[6], sg[6], fmax_[6];
+    for (int i = 0; i < 6; i++) {
+        const bool fr = (flags & F_FRICTIONLOSS) != 0u;
+        r.Rf[i] = T((1.0 - so100g::SOLIMP_D0)/so100g::SOLIMP_D0 * so100g::DOF_INVWEIGHT0[i]);
+        r.cfv[i] = Bd*v[i];
+        r.bf[i] = r.a0[i] + Bd*v[i];                          // J a0 - aref, aref = -B v
+        r.fmax_[i] = fr ? T(so100g::FRICTIONLOSS) : T(0);
+        if (!fr) ff[i] = T(0);
+        const T dlo = q[i] - T(so100g::JNT_RANGE[i][0]), dhi = T(so100g::JNT_RANGE[i][1]) - q[i];
+        const bool lo = dlo < T(0), hi = dhi < T(0);
+        const bool act = (flags & F_LIMITS) != 0u && (lo || hi);
+        const T dist = lo ? dlo : dhi;
+        r.sg[i] = lo ? T(1) : T(-1);
+        const T imp = impedance(tabs(dist));
+        r.Rl[i] = (T(1) - imp)*trcp(imp) * T(so100g::DOF_INVWEIGHT0[i]);
+        r.clv[i] = Bd*r.sg[i]*v[i] + Kd*imp*dist;
+        r.bl[i] = r.sg[i]*r.a0[i] + Bd*r.sg[i]*v[i] + Kd*imp*dist;
+        if (!act) { fl[i] = T(0); r.sg[i] = T(0); }          // inactive row: force pinned at 0
+        else fl[i] = tmax(fl[i], T(0));
+    }
+}
+
+template <typename T>
+SO100_HD void arm_pgs(T ff[6], T fl[6], int iters, const Arm<T>& A, const ArmRows<T>& r, T acc[6], T& residual) {
+    const T* Minv = A.Minv;
+    const T* Rf = r.Rf; const T* Rl = r.Rl; const T* sg = r.sg; const T* bf = r.bf; const T* bl = r.bl; const T* fmax_ = r.fmax_;
+    // Block Gauss-Seidel over JOINTS: the friction row and the limit row of one joint are collinear
+    // (J = e_i and sg_i e_i), so scalar PGS crawls when both are active (rate a^2/((a+Rf)(a+Rl)) ~ 0.84).
+    // Each joint's 2-row box QP  min 1/2 [f l] [[a+Rf, sg a],[sg a, a+Rl]] [f l]' + [f l].[cf cl],
+    // |f| <= fmax, l >= 0  is solved exactly by enumerating its active sets; the coupling between joints
+    // (armature-dominated M => nearly diagonal Minv) then converges in a few sweeps.
+    T tq[6];                                              // joint-space constraint torque J^T f
+    T rAf[6], rAl[6], rdet[6];                            // sweep-invariant reciprocals of the 2x2 blocks
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const bool fr = (flags & F_FRICTIONLOSS) != 0u;
-            Rf[i] = T((1.0 - so100g::SOLIMP_D0)/so100g::SOLIMP_D0 * so100g::DOF_INVWEIGHT0[i]);
-            bf[i] = a0[i] + Bd*v[i];                          // J a0 - aref, aref = -B v
-            fmax_[i] = fr ? T(so100g::FRICTIONLOSS) : T(0);
-            if (!fr) ff[i] = T(0);
-            const T dlo = q[i] - T(so100g::JNT_RANGE[i][0]), dhi = T(so100g::JNT_RANGE[i][1]) - q[i];
-            const bool lo = dlo < T(0), hi = dhi < T(0);
-            const bool act = (flags & F_LIMITS) != 0u && (lo || hi);
-            const T dist = lo ? dlo : dhi;
-            sg[i] = lo ? T(1) : T(-1);
-            const T imp = impedance(tabs(dist));
-            Rl[i] = (T(1) - imp)*trcp(imp) * T(so100g::DOF_INVWEIGHT0[i]);
-            bl[i] = sg[i]*a0[i] + Bd*sg[i]*v[i] + Kd*imp*dist;
-            if (!act) { fl[i] = T(0); sg[i] = T(0); }          // inactive row: force pinned at 0
-            else fl[i] = tmax(fl[i], T(0));
-        }
-        // Block Gauss-Seidel over JOINTS: the friction row and the limit row of one joint are collinear
-        // (J = e_i and sg_i e_i), so scalar PGS crawls when both are active (rate a^2/((a+Rf)(a+Rl)) ~ 0.84).
-        // Each joint's 2-row box QP  min 1/2 [f l] [[a+Rf, sg a],[sg a, a+Rl]] [f l]' + [f l].[cf cl],
-        // |f| <= fmax, l >= 0  is solved exactly by enumerating its active sets; the coupling between joints
-        // (armature-dominated M => nearly diagonal Minv) then converges in a few sweeps.
-        T tq[6];                                              // joint-space constraint torque J^T f
-        T rAf[6], rAl[6], rdet[6];                            // sweep-invariant reciprocals of the 2x2 blocks
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            tq[i] = ff[i] + sg[i]*fl[i];
-            const T a = sym6(Minv, i, i), Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a;
-            rAf[i] = trcp(Af); rAl[i] = trcp(Al); rdet[i] = trcp(Af*Al - cx*cx);
-        }
-        for (int it = 0; it < iters; it++) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                T w = T(0);
-#pragma unroll
-                for (int j = 0; j < 6; j++) w += sym6(Minv, i, j)*tq[j];
-                const T a = sym6(Minv, i, i);
-                const T wo = w - a*tq[i];                     // contribution of the other joints
-                const T cf = bf[i] + wo, cl = bl[i] + sg[i]*wo;
-                const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a, F = fmax_[i];
-                // (1) limit row inactive
-                const T f1 = tclamp(-cf*rAf[i], -F, F);
-                const bool ok1 = (sg[i] == T(0)) || (cl + cx*f1 >= T(0));
-                // (2) both interior
-                const T f2 = (cx*cl - cf*Al)*rdet[i], l2 = (cx*cf - Af*cl)*rdet[i];
-                const bool ok2 = tabs(f2) <= F && l2 >= T(0);
-                // (3) friction saturated, limit active
-                const T lp = tmax(-(cl + cx*F)*rAl[i], T(0)), lm = tmax(-(cl - cx*F)*rAl[i], T(0));
-                const bool okp = cf + Af*F + cx*lp <= T(0);
-                const T f3 = okp ? F : -F, l3 = okp ? lp : lm;
-                const T fn = ok1 ? f1 : (ok2 ? f2 : f3);
-                const T ln = ok1 ? T(0) : (ok2 ? l2 : l3);
-                ff[i] = fn; fl[i] = ln;
-                tq[i] = fn + sg[i]*ln;
-            }
-        }
+    for (int i = 0; i < 6; i++) {
+        tq[i] = ff[i] + sg[i]*fl[i];
+        const T a = sym6(Minv, i, i), Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a;
+        rAf[i] = trcp(Af); rAl[i] = trcp(Al); rdet[i] = trcp(Af*Al - cx*cx);
+    }
+    T change = T(0);                                      // largest |d acc_i| caused by the LAST sweep: the residual a caller can watch
+    for (int it = 0; it < iters; it++) {
+        change = T(0);
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            T t = a0[i];
+            T w = T(0);
 #pragma unroll
-            for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tq[j];
-            acc[i] = t;
+            for (int j = 0; j < 6; j++) w += sym6(Minv, i, j)*tq[j];
+            const T a = sym6(Minv, i, i);
+            const T wo = w - a*tq[i];                     // contribution of the other joints
+            const T cf = bf[i] + wo, cl = bl[i] + sg[i]*wo;
+            const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a, F = fmax_[i];
+            // (1) limit row inactive
+            const T f1 = tclamp(-cf*rAf[i], -F, F);
+            const bool ok1 = (sg[i] == T(0)) || (cl + cx*f1 >= T(0));
+            // (2) both interior
+            const T f2 = (cx*cl - cf*Al)*rdet[i], l2 = (cx*cf - Af*cl)*rdet[i];
+            const bool ok2 = tabs(f2) <= F && l2 >= T(0);
+            // (3) friction saturated, limit active
+            const T lp = tmax(-(cl + cx*F)*rAl[i], T(0)), lm = tmax(-(cl - cx*F)*rAl[i], T(0));
+            const bool okp = cf + Af*F + cx*lp <= T(0);
+            const T f3 = okp ? F : -F, l3 = okp ? lp : lm;
+            const T fn = ok1 ? f1 : (ok2 ? f2 : f3);
+            const T ln = ok1 ? T(0) : (ok2 ? l2 : l3);
+            ff[i] = fn; fl[i] = ln;
+            const T tn = fn + sg[i]*ln;
+            change = tmax(change, tabs(tn - tq[i])*a);
+            tq[i] = tn;
         }
     }
+    residual = change;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        T t = r.a0[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) t += sym6(Minv, i, j)*tq[j];
+        acc[i] = t;
+    }
+}
+
+template <typename T>
+SO100_HD void arm_integrate(T q[6], T v[6], T qc[6], const T acc[6], T dq[6]) {
     const T h = T(so100g::TIMESTEP);
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -561,6 +580,31 @@ SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff
         q[i] = t;
         dq[i] = y;                              // the (compensated) increment: what the next substep's trig update rotates by
     }
+}
+
+template <typename T>
+SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6],
+                                  T* residual = nullptr, T* acc_out = nullptr) {
+    // (A.M / A.Dinv / A.Minv hold this substep's factorised mass matrix, A.bias its bias force)
+    T tau[6], acc[6];
+    arm_tau(q, v, ctrl, A, tau);
+    const bool constrained = (flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u;
+    if (!constrained) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc[i] = tau[i];
+        ldl6_solve(A.M, A.Dinv, acc);
+    } else {
+        ArmRows<T> r;
+        arm_rows(q, v, tau, ff, fl, flags, A, r);
+        T res;
+        arm_pgs(ff, fl, iters, A, r, acc, res);
+        if (residual) *residual = tmax(*residual, res);
+    }
+    if (acc_out) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) acc_out[i] = acc[i];
+    }
+    arm_integrate(q, v, qc, acc, dq);
 }
 
 template <typename T>

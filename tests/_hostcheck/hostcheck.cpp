@@ -53,6 +53,47 @@ void hc_sincos_f(float x, float* s, float* c) { tsincos<float>(x, *s, *c); }
 void hc_dbg_counters(long* out) { out[0] = g_dbg_newton_iters; out[1] = g_dbg_newton_ls; }
 }
 
+// ---- finger-pad contacts (so100_contact.hpp): whole substeps of one env, fp64 and fp32 ----------------------------------------
+#include "../../so100_mujoco_rl_amd/csrc/so100_contact.hpp"
+// state: q6 v6 ff6 fl6 aw6 | cube pos3 quat4 vel6 warm6  (49 doubles); stat: per substep max of [contacts, coupled, dropped], [3] = max residual*1e9
+template <typename T> static void csub(double* st, const double* ctrl, const double* applied, unsigned flags, int iters, int citers, int n, int* stat) {
+    T q[6], v[6], ff[6], fl[6], aw[6], qc[6] = {0,0,0,0,0,0}, cc[6], ap[3] = { (T)applied[0], (T)applied[1], (T)applied[2] };
+    Cube<T> cb;
+    for (int i = 0; i < 6; i++) { q[i] = (T)st[i]; v[i] = (T)st[6+i]; ff[i] = (T)st[12+i]; fl[i] = (T)st[18+i]; aw[i] = (T)st[24+i]; cc[i] = (T)ctrl[i]; }
+    for (int i = 0; i < 3; i++) cb.pos[i] = (T)st[30+i];
+    for (int i = 0; i < 4; i++) cb.quat[i] = (T)st[33+i];
+    for (int i = 0; i < 6; i++) { cb.vel[i] = (T)st[37+i]; cb.warm[i] = (T)st[43+i]; }
+    Arm<T> A; T dq[6] = {0,0,0,0,0,0}; T res = T(0);
+    stat[0] = stat[1] = stat[2] = stat[3] = 0;
+    for (int s = 0; s < n; s++) {
+        int sst[3];
+        substep_with_pads<T>(q, v, qc, cc, ff, fl, aw, cb, ap, flags, iters, citers, A, (s % 16) == 0, dq, &res, sst);
+        for (int k = 0; k < 3; k++) stat[k] = sst[k] > stat[k] ? sst[k] : stat[k];
+    }
+    stat[3] = (int)(res*1e9 > 2e9 ? 2e9 : res*1e9);
+    for (int i = 0; i < 6; i++) { st[i] = q[i]; st[6+i] = v[i]; st[12+i] = ff[i]; st[18+i] = fl[i]; st[24+i] = aw[i]; }
+    for (int i = 0; i < 3; i++) st[30+i] = cb.pos[i];
+    for (int i = 0; i < 4; i++) st[33+i] = cb.quat[i];
+    for (int i = 0; i < 6; i++) { st[37+i] = cb.vel[i]; st[43+i] = cb.warm[i]; }
+}
+template <typename T> static int bb(const double* cA, const double* RA, const double* hA, const double* cB, const double* RB, const double* hB, double* pos, double* nrm, double* dist) {
+    T a[3], ra[9], ha[3], b[3], rb[9], hb[3], n[3];
+    for (int i = 0; i < 3; i++) { a[i] = (T)cA[i]; ha[i] = (T)hA[i]; b[i] = (T)cB[i]; hb[i] = (T)hB[i]; }
+    for (int i = 0; i < 9; i++) { ra[i] = (T)RA[i]; rb[i] = (T)RB[i]; }
+    int k = 0;
+    const int cnt = box_box<T>(a, ra, ha, b, rb, hb, n, [&](const T* p, T d) { pos[3*k] = p[0]; pos[3*k+1] = p[1]; pos[3*k+2] = p[2]; dist[k] = d; k++; });
+    for (int i = 0; i < 3; i++) nrm[i] = n[i];
+    return cnt;
+}
+extern "C" {
+void hc_csub_d(double* st, const double* ctrl, const double* ap, unsigned fg, int it, int cit, int n, int* stat) { csub<double>(st, ctrl, ap, fg, it, cit, n, stat); }
+void hc_csub_f(double* st, const double* ctrl, const double* ap, unsigned fg, int it, int cit, int n, int* stat) { csub<float>(st, ctrl, ap, fg, it, cit, n, stat); }
+int hc_boxbox_d(const double* cA, const double* RA, const double* hA, const double* cB, const double* RB, const double* hB, double* pos, double* nrm, double* dist) { return bb<double>(cA, RA, hA, cB, RB, hB, pos, nrm, dist); }
+int hc_boxbox_f(const double* cA, const double* RA, const double* hA, const double* cB, const double* RB, const double* hB, double* pos, double* nrm, double* dist) { return bb<float>(cA, RA, hA, cB, RB, hB, pos, nrm, dist); }
+void hc_cdbg_trace(int on) { g_dbg_cnewton_trace = on; }
+void hc_cdbg_counters(long* out) { out[0] = g_dbg_cnewton_calls; out[1] = g_dbg_cnewton_iters; out[2] = g_dbg_cnewton_ls; }
+}
+
 // ---- the full task layer (so100_task.hpp) on the host, fp32, one env ------------------------------------------------
 #include "../../so100_mujoco_rl_amd/csrc/so100_task.hpp"
 namespace { 
