@@ -105,7 +105,8 @@ def cpu_baseline(kind, flags, iters, seconds=12.0):
         b.step(acts, threads=threads); steps += 1
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "host_cpus": cores, "kind": "port",
-            "sample": f"{n} Env{kind:02d} envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads on a {cores}-CPU host, same flags/solver iterations"}
+            "sample": f"{n} Env{kind:02d} envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {threads} threads on a {cores}-CPU host, same flags, "
+                      + ("primal Newton to convergence" if iters < 0 else f"{iters} PGS sweeps")}
 
 
 def sb3_vecenv_path(kind, flags, n, dev, steps=200):
@@ -393,7 +394,7 @@ def main():
         if world == 1 and not args.no_sb3_path:
             out["sb3_vecenv_path"] = sb3_vecenv_path(kind, flags, n, dev)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, flags, 2)
+            out["cpu_baseline"] = cpu_baseline(kind, flags, -1 if (flags & CONTACT_BITS) else 2)     # pad rows: the oracle's Newton (PGS crawls on them)
         if world == 1 and args.workload == "env01_free" and not args.no_large_batch:
             out["roofline"]["large_batch"] = large_batch_roofline(kind, flags, dev)
         sys.stdout.flush()

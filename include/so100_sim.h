@@ -41,7 +41,15 @@ extern "C" {
 #define SO100_F_LIMITS       2u   /* joint range limits (model/so_arm100_camera.xml:35-50)           */
 #define SO100_F_FLOOR        4u   /* cube / floor box-plane contact (model/env01.xml:32,39)          */
 #define SO100_F_CUBE_PINNED  8u   /* cube kinematic (BASELINE.json configs[1]: "contact disabled")   */
-#define SO100_F_REFERENCE (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR)
+#define SO100_F_PADS_FLOOR  16u   /* the 8 finger-pad boxes vs the floor plane (so_arm100_camera.xml:108-111,120-123; env01.xml:39):
+                                     live in the reference scene                                                           */
+#define SO100_F_PADS_CUBE   32u   /* the finger pads vs the cube: excluded in the reference scene (env01.xml:47-48); lifting
+                                     that exclusion is BASELINE.json configs[4] ("arm-cube collision")                    */
+/* what the reference scene simulates, as far as it can be reproduced: the arm's mesh geoms (class "collision",
+ * so_arm100_camera.xml:58-59) are not in the reference snapshot, so link-vs-floor / link-vs-link mesh contacts are absent */
+#define SO100_F_REFERENCE (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_PADS_FLOOR)
+#define SO100_F_NOPADS    (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR)   /* round-1 "reference": no arm contact at all */
+#define SO100_F_CONTACT5  (SO100_F_REFERENCE | SO100_F_PADS_CUBE)                   /* BASELINE.json configs[4]                   */
 
 #define SO100_E_INVALID  (-1)     /* bad argument                                   */
 #define SO100_E_NODEVICE (-2)     /* no usable HIP device / HIP runtime failure      */

@@ -748,7 +748,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, const T* L6, cons
 template <typename T, class Store>
 SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], unsigned flags, int iters,
                                       Arm<T>& A, const WorldFK<T>& W, const Store& cs, bool coupled, Cube<T>& cube, const T Rc[9],
-                                      const T applied[3], T dq[6], T* residual) {
+                                      const T applied[3], T dq[6], T* residual, T* xcube_out = nullptr) {
     T tau[6], acc[6];
     arm_tau(q, v, ctrl, A, tau);
     ArmRows<T> r;
@@ -775,11 +775,16 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
         res = primal_newton<12>(P, A.M, A.Dinv, iters, x);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[i] = x[i];
-        // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
+        if (xcube_out) {                                      // multi-wave kernels: the wave that owns the cube integrates it
 #pragma unroll
-        for (int i = 0; i < 3; i++) { cube.warm[i] = x[6 + i] - a0c[i]; cube.warm[3 + i] = x[9 + i]; }
-        const T al[3] = { x[6], x[7], x[8] }, aa[3] = { x[9], x[10], x[11] };
-        cube_integrate(cube, al, aa);
+            for (int i = 0; i < 6; i++) xcube_out[i] = x[6 + i];
+        } else {
+            // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
+#pragma unroll
+            for (int i = 0; i < 3; i++) { cube.warm[i] = x[6 + i] - a0c[i]; cube.warm[3 + i] = x[9 + i]; }
+            const T al[3] = { x[6], x[7], x[8] }, aa[3] = { x[9], x[10], x[11] };
+            cube_integrate(cube, al, aa);
+        }
     }
     if (residual) *residual = tmax(*residual, res);
     // row forces of the solution -> the block PGS's warm-start memory (a lane may be back on that path next substep)

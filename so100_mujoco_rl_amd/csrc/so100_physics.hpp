@@ -608,19 +608,19 @@ SO100_HD void arm_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff
 }
 
 template <typename T>
-SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6]) {
+SO100_HD void arm_finish(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A, T dq[6], T* residual = nullptr) {
     arm_factor(flags, A);
-    arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, iters, A, dq);
+    arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, iters, A, dq, residual);
 }
 
 template <typename T>
 SO100_HD void arm_substep(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], unsigned flags, int iters, Arm<T>& A,
-                          bool first, T dq[6]) {
+                          bool first, T dq[6], T* residual = nullptr) {
     // first substep of an env step: exact sin/cos; later ones: incremental update by the previous substep's increment
     if (first) arm_trig(q, A); else arm_trig_update(q, dq, A);
     arm_bias(v, A);
     arm_mass(A);
-    arm_finish(q, v, qc, ctrl, ff, fl, flags, iters, A, dq);
+    arm_finish(q, v, qc, ctrl, ff, fl, flags, iters, A, dq, residual);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -59,15 +59,26 @@ struct Prof {
 // On return (wave 0): e.q/v/qc/ff/fl/cube updated, A.s / A.c = sin/cos the LAST substep started from, cstale = the
 // cube position it started from (Q1).
 // ---------------------------------------------------------------------------------------------------------------
-template <class Hook>
+// With the finger-pad contact flags (PADS): wave 3 -- idle otherwise -- runs the world-frame kinematics and the narrowphase
+// (pad/floor, pad/cube) of the substep concurrently with RNEA / CRBA and leaves the contact records in LDS (cbuf, [record]
+// [field][lane]); after the mid-substep barrier wave 0 solves lanes that have contacts in the primal (so100_contact.hpp) and
+// the others with the block PGS as before.  A lane whose pad touches the cube solves arm + cube together on wave 0 and hands
+// the cube's acceleration to wave 2 (which owns the cube state) through LDS: one more barrier per substep, only in kernels
+// compiled with F_PADS_CUBE.  xa: [8][64] floats -- rows 0-5 the cube acceleration of coupled lanes, row 6 the lane's
+// contact code (count | coupled << 8 | dropped << 16).
+template <bool PADS, class Hook>
 __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, const float ctrl[6], float cstale[3],
-                                                 Arm<float>& A, float (&xq)[18][64], float (&xc)[24][64], float (&xb)[6][64], Prof& prof_, Hook after_first_barrier) {
+                                                 Arm<float>& A, float (&xq)[18][64], float (&xc)[24][64], float (&xb)[6][64],
+                                                 float* cbuf, float (*xa)[64], Prof& prof_, Hook after_first_barrier) {
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-    // The cube is dynamically independent of the arm: when it is simulated (not pinned) wave 2 owns it for the
-    // substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
+    // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
+    // for the substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
     const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
+    const bool pads = PADS && (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
+    const bool padcube = PADS && (p.flags & F_PADS_CUBE) != 0u && cube_live;
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
+    if (wave == 0) { e.res = 0.0f; e.cstat = 0; }
     if (cube_live) {
         if (wave == 0) {
 #pragma unroll
@@ -100,6 +111,14 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
             SO100_PROF(2);                                 // trig (wave 0)
         }
+        if (padcube && wave == 2 && sub > 0) {             // the cube's pose for this substep's narrowphase / coupled solve
+#pragma unroll
+            for (int i = 0; i < 3; i++) xc[i][lane] = cb.pos[i];
+#pragma unroll
+            for (int i = 0; i < 4; i++) xc[3 + i][lane] = cb.quat[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xc[7 + i][lane] = cb.vel[i]; xc[13 + i][lane] = cb.warm[i]; }
+        }
         __syncthreads();
         SO100_PROF(3);                                     // barrier 1 wait
         after_first_barrier(sub);
@@ -119,15 +138,82 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
             cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
             SO100_PROF(4);                                 // cube_prepare (wave 2)
+        } else if (wave == 3 && pads) {
+            // world FK of the joint frames + pad narrowphase -> contact records in LDS
+            float s3[6], c3[6], v3[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) { s3[i] = xq[i][lane]; c3[i] = xq[6 + i][lane]; v3[i] = xq[12 + i][lane]; }
+            WorldFK<float> W;
+            world_fk<float>(s3, c3, W);
+            Cube<float> c3b; float Rc[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
+            if (padcube) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) c3b.pos[i] = xc[i][lane];
+                float qn[4] = { xc[3][lane], xc[4][lane], xc[5][lane], xc[6][lane] };
+#pragma unroll
+                for (int i = 0; i < 6; i++) c3b.vel[i] = xc[7 + i][lane];
+                quat_normalize(qn); quat_to_mat(qn, Rc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; i++) c3b.pos[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) c3b.vel[i] = 0.0f;
+            }
+            ContactsLds<float> cs{ cbuf, lane };
+            const bool coupled = detect_pad_contacts<float>(W, v3, c3b, Rc, p.flags, padcube, cs);
+            xa[6][lane] = __int_as_float(cs.n | (coupled ? 256 : 0) | ((cs.dropped > 0xFFFF ? 0xFFFF : cs.dropped) << 16));
+            SO100_PROF(4);
         }
         __syncthreads();
         SO100_PROF(5);                                     // barrier 2 wait
-        if (wave == 2 && cube_live) { cube_finish<float>(cb, p.flags, p.contact_iters, cprep); SO100_PROF(6); }   // ... Newton + Euler behind the arm's solve
+        float cal[3], caa[3];
+        if (wave == 2 && cube_live) { cube_solve<float>(cb, p.flags, p.contact_iters, cprep, cal, caa); SO100_PROF(6); }   // Newton behind the arm's solve
         if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
-            arm_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq);
+            const int code = pads ? __float_as_int(xa[6][lane]) : 0;
+            const int nc = code & 255;
+            if (nc > 0) {
+                const bool coupled = (code & 256) != 0;
+                WorldFK<float> W;
+                world_fk<float>(A.s, A.c, W);
+                ContactsLds<float> cs{ cbuf, lane }; cs.n = nc;
+                Cube<float> ct; float Rc[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
+                float ap[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
+#pragma unroll
+                for (int i = 0; i < 3; i++) ct.pos[i] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 6; i++) ct.warm[i] = 0.0f;
+                if (coupled) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) ct.pos[i] = xc[i][lane];
+                    float qn[4] = { xc[3][lane], xc[4][lane], xc[5][lane], xc[6][lane] };
+#pragma unroll
+                    for (int i = 0; i < 6; i++) ct.warm[i] = xc[13 + i][lane];
+                    quat_normalize(qn); quat_to_mat(qn, Rc);
+                }
+                float xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+                contact_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, p.flags, p.contact_iters, A, W, cs, coupled, ct, Rc, ap, dq, &e.res, xcube);
+                if (coupled) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) xa[i][lane] = xcube[i];
+                }
+            } else {
+                arm_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq, &e.res, pads ? e.aw : nullptr);
+            }
+            if (pads) {
+                const int n0 = e.cstat & 255, dr = (e.cstat >> 8) + (code >> 16);
+                e.cstat = (nc > n0 ? nc : n0) | ((dr > 0xFFFF ? 0xFFFF : dr) << 8);
+            }
             SO100_PROF(6);                                 // solve + integrate (wave 0)
+        }
+        if (padcube) __syncthreads();                      // coupled lanes: the cube's acceleration comes from wave 0's 12-dof solve
+        if (wave == 2 && cube_live) {
+            if (padcube && (__float_as_int(xa[6][lane]) & 256) != 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { cal[i] = xa[i][lane]; caa[i] = xa[3 + i][lane]; cb.warm[i] = cal[i] - cprep.a0[i]; cb.warm[3 + i] = caa[i]; }
+            }
+            cube_integrate<float>(cb, cal, caa);
         }
     }
     if (cube_live) {
@@ -306,8 +392,13 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     constexpr int LD = 65;                                        // LDS row stride of the [env][unit] activation images
     __shared__ __attribute__((aligned(16))) float hd[6*64 + 64 + 16];   // mu_w | v_w | mu_b(6) log_std(6) v_b(1)
     __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
-    __shared__ float h1t[2][64][LD];
-    __shared__ float h2t[2][64][LD];
+    // both hidden-activation images in one array: they are dead during the physics phase, when the pad-contact records
+    // ([MAXC][CF][64] floats = 61 440 B) live in the same bytes
+    __shared__ float hbuf[2][2][64][LD];
+    float (*h1t)[64][LD] = hbuf[0]; float (*h2t)[64][LD] = hbuf[1];
+    static_assert(sizeof(hbuf) >= sizeof(float)*MAXC*CF*64, "contact records must fit under the activation images");
+    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
+    __shared__ float xa[PADS ? 8 : 1][64];                        // pad contacts: cube acceleration of coupled lanes + per-lane contact code
     __shared__ float xmean[6][64];                                // action means, two per wave (waves 0, 1, 3 -> wave 0)
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
     __shared__ float xq[18][64];                                  // physics split: sin q, cos q, v of env = lane (wave 0 -> wave 1)
@@ -346,7 +437,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     }
     EnvState e;
     if (wave == 0) {
-        if (live) load_env_state<KIND>(state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
+        if (live) load_env_state<KIND, FL>(state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
 #pragma unroll
         for (int k = 0; k < ODP; k++) oxt[lane][k] = (live && k < OD) ? ra.obs_in[(size_t)env*OD + k] : 0.0f;
     }
@@ -453,7 +544,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
-            physics_phase_mw(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, prof_, [&](int sub) {
+            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, &hbuf[0][0][0][0], xa, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
                     policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
@@ -492,7 +583,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     }
     if (wave < 3) SO100_PROF_FLUSH(8*wave);
     if (wave == 0 && live) {
-        store_env_state<KIND>(state, p.n, env, e);
+        store_env_state<KIND, FL>(state, p.n, env, e);
         if (ra.T > 0) {
 #pragma unroll
             for (int k = 0; k < OD; k++) obs_out[(size_t)env*OD + k] = last_obs[k];

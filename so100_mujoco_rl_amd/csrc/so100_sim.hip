@@ -18,9 +18,9 @@
 
 namespace so100 {
 // ---- SoA load / store of one env ----------------------------------------------------------------------
-template <int KIND> __device__ __forceinline__ void load_env_state(const float* __restrict__ S, int n, int env, EnvState& e) {
+template <int KIND, int FL = -1> __device__ __forceinline__ void load_env_state(const float* __restrict__ S, int n, int env, EnvState& e) {
 #define X(name, member, kind, group) \
-    if constexpr (uses_group<KIND>(group)) { const float w_ = S[(size_t)SF_##name*n + env]; \
+    if constexpr (uses_group<KIND, FL>(group)) { const float w_ = S[(size_t)SF_##name*n + env]; \
         if constexpr (#kind[0] == 'i') e.member = __float_as_int(w_); else e.member = w_; }
     SO100_STATE_FIELDS(X)
 #undef X
@@ -28,9 +28,9 @@ template <int KIND> __device__ __forceinline__ void load_env_state(const float* 
 template <typename M> __device__ __forceinline__ float as_word(M v) {
     if constexpr (sizeof(M) == 4 && !__is_floating_point(M)) return __int_as_float((int)v); else return (float)v;
 }
-template <int KIND> __device__ __forceinline__ void store_env_state(float* __restrict__ S, int n, int env, const EnvState& e) {
+template <int KIND, int FL = -1> __device__ __forceinline__ void store_env_state(float* __restrict__ S, int n, int env, const EnvState& e) {
 #define X(name, member, kind, group) \
-    if constexpr (uses_group<KIND>(group)) S[(size_t)SF_##name*n + env] = as_word(e.member);
+    if constexpr (uses_group<KIND, FL>(group)) S[(size_t)SF_##name*n + env] = as_word(e.member);
     SO100_STATE_FIELDS(X)
 #undef X
 }
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
     EnvState e;
-    load_env_state<KIND>(io.state, p.n, env, e);
+    load_env_state<KIND, FL>(io.state, p.n, env, e);
     float a[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) a[i] = io.act[(size_t)env*6 + i];
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
     float obs[OD], tobs[OD];
     const float* inj = io.inject ? io.inject + (size_t)env*SO100_NINJECT : nullptr;
     const StepResult r = env_step_vec<KIND>(e, a, p, p.env_id_offset + (uint32_t)env, inj, io.start_tab, obs, tobs);
-    store_env_state<KIND>(io.state, p.n, env, e);
+    store_env_state<KIND, FL>(io.state, p.n, env, e);
 #pragma unroll
     for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];
     io.rew[env] = r.reward;
@@ -110,6 +110,9 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     __shared__ float xq[18][64];
     __shared__ float xc[24][64];
     __shared__ float xb[6][64];
+    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
+    __shared__ float cbuf[PADS ? MAXC*CF*64 : 1];                 // pad contact records [record][field][lane]
+    __shared__ float xa[PADS ? 8 : 1][64];
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,7 +122,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     EnvState e; StepCtx ctx{}; float u[8] = {}; float cstale[3] = {};
     const float* inj = (io.inject && live) ? io.inject + (size_t)env*SO100_NINJECT : nullptr;
     if (wave == 0) {
-        if (live) load_env_state<KIND>(io.state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
+        if (live) load_env_state<KIND, FL>(io.state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
         float a[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) a[i] = live ? io.act[(size_t)env*6 + i] : 0.0f;
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
         env_step_pre<KIND>(e, a, u, p, ctx);
     }
     Arm<float> A; Prof prof_;
-    physics_phase_mw(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, prof_, [](int) {});
+    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, cbuf, xa, prof_, [](int) {});
     if (wave != 0 || !live) return;
     e.nsub += p.frame_skip;
     TaskPoses<float> P;
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     float obs[OD], tobs[OD]; bool term;
     const float reward = env_step_post<KIND>(e, ctx, u, P, cstale, obs, term);
     const StepResult r = env_step_finish<KIND>(e, reward, term, p, p.env_id_offset + (uint32_t)env, inj, io.start_tab, obs, tobs);
-    store_env_state<KIND>(io.state, p.n, env, e);
+    store_env_state<KIND, FL>(io.state, p.n, env, e);
 #pragma unroll
     for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];
     io.rew[env] = r.reward;
@@ -230,7 +233,9 @@ template <int KIND> int launch_step(so100_sim* s, const StepPtrs& io, hipStream_
     switch (s->prm.flags) {
     case SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_CUBE_PINNED); break;
     case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED); break;
+    case SO100_F_NOPADS: SO100_STEP(SO100_F_NOPADS); break;
     case SO100_F_REFERENCE: SO100_STEP(SO100_F_REFERENCE); break;
+    case SO100_F_CONTACT5: if constexpr (reach_kind<KIND>()) { SO100_STEP(SO100_F_CONTACT5); } else { SO100_STEP(-1); } break;
     default: SO100_STEP(-1); break;
     }
 #undef SO100_STEP
@@ -277,8 +282,10 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     if (cfg->contact_iters < 1 || cfg->contact_iters > 64) return fail(SO100_E_INVALID, "so100_create: contact_iters must be in 1..64%s");
     if (cfg->frame_skip < 1 || cfg->frame_skip > 1024) return fail(SO100_E_INVALID, "so100_create: frame_skip must be in 1..1024%s");
     if (cfg->max_episode_steps < 0) return fail(SO100_E_INVALID, "so100_create: max_episode_steps must be >= 0%s");
-    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED))
+    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
         return fail(SO100_E_INVALID, "so100_create: unknown flag bits%s");
+    if ((cfg->flags & SO100_F_PADS_CUBE) && (cfg->flags & SO100_F_CUBE_PINNED))
+        return fail(SO100_E_INVALID, "so100_create: SO100_F_PADS_CUBE needs a dynamic cube (not SO100_F_CUBE_PINNED)%s");
     if ((cfg->flags & SO100_F_FLOOR) && (cfg->flags & SO100_F_CUBE_PINNED))
         return fail(SO100_E_INVALID, "so100_create: SO100_F_FLOOR and SO100_F_CUBE_PINNED are mutually exclusive%s");
     int ndev = 0;
@@ -375,7 +382,10 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
 #define SO100_RL(KIND, FLV, NW) hipLaunchKernelGGL((so100_rollout_fused<KIND, FLV, NW>), grid, dim3(64*NW), 0, st, s->prm, s->state, s->start_tab, \
         io->obs_dev, io->rew_dev, io->done_dev, io->trunc_dev, io->terminal_obs_dev, io->ep_return_dev, io->ep_length_dev, pw, ra)
 #define SO100_RL_FL(KIND, NW) do { if (s->prm.flags == SO100_F_CUBE_PINNED) SO100_RL(KIND, SO100_F_CUBE_PINNED, NW); \
-        else if (s->prm.flags == SO100_F_REFERENCE) SO100_RL(KIND, SO100_F_REFERENCE, NW); else SO100_RL(KIND, -1, NW); } while (0)
+        else if (s->prm.flags == SO100_F_NOPADS) SO100_RL(KIND, SO100_F_NOPADS, NW); \
+        else if (s->prm.flags == SO100_F_REFERENCE) SO100_RL(KIND, SO100_F_REFERENCE, NW); \
+        else if (s->prm.flags == SO100_F_CONTACT5 && (KIND <= 2 || KIND == 6)) SO100_RL(KIND <= 2 || KIND == 6 ? KIND : 1, SO100_F_CONTACT5, NW); \
+        else SO100_RL(KIND, -1, NW); } while (0)
 #define SO100_RL_KIND(NW) switch (s->cfg.env_kind) { case 1: SO100_RL_FL(1, NW); break; case 2: SO100_RL_FL(2, NW); break; \
         case 3: SO100_RL_FL(3, NW); break; case 4: SO100_RL_FL(4, NW); break; case 5: SO100_RL_FL(5, NW); break; default: SO100_RL_FL(6, NW); }
     SO100_RL_KIND(4)

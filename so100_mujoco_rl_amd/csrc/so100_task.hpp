@@ -10,6 +10,7 @@
 #pragma once
 #include "so100_physics.hpp"
 #include "so100_cube.hpp"
+#include "so100_contact.hpp"
 #include <stdint.h>
 
 namespace so100 {
@@ -41,10 +42,15 @@ struct EnvState {
     float lc[2]; int lost;      // last detected centre, lost counter (ref: env03_v1.py:152-164)
     float tgt[3], tdt, ttime;   // cube target, dwell, time of last retarget (ref: env03_v1.py:77-93)
     float av[6];                // last "angular velocities" (ref: env_base_01.py:165-178)
+    float res;                  // largest constraint-solver residual of the last env step: the acceleration change of the last
+                                // block-PGS sweep, or the last Newton step of the contact solve when it ran out of iterations
+    float aw[6];                // arm qacc of the previous substep: warm start of the pad-contact Newton (so100_contact.hpp)
+    int   cstat;                // pad contacts: most contacts in a substep of the last env step | (dropped over the budget) << 8
 };
 
 // The [field][N] state matrix.  X(name, member, kind, group): kind f = float, i = int32;
-// group 0 = all env kinds, 1 = Env01/02/06 (reach family), 2 = Env02/06 (block memory), 3 = Env03-05 (look-at family).
+// group 0 = all env kinds, 1 = Env01/02/06 (reach family), 2 = Env02/06 (block memory), 3 = Env03-05 (look-at family),
+// 4 = any constraint rows simulated (flags & (friction | limits | pads)), 5 = finger-pad contacts simulated (flags & pads).
 #define SO100_STATE_FIELDS(X) \
     X(q0, q[0], f, 0) X(q1, q[1], f, 0) X(q2, q[2], f, 0) X(q3, q[3], f, 0) X(q4, q[4], f, 0) X(q5, q[5], f, 0) \
     X(cube_x, cube.pos[0], f, 0) X(cube_y, cube.pos[1], f, 0) X(cube_z, cube.pos[2], f, 0) \
@@ -65,7 +71,10 @@ struct EnvState {
     X(cmd0, cmd[0], f, 3) X(cmd1, cmd[1], f, 3) X(cmd2, cmd[2], f, 3) X(cmd3, cmd[3], f, 3) X(cmd4, cmd[4], f, 3) X(cmd5, cmd[5], f, 3) \
     X(lc_x, lc[0], f, 3) X(lc_y, lc[1], f, 3) X(lost_count, lost, i, 3) \
     X(tgt_x, tgt[0], f, 3) X(tgt_y, tgt[1], f, 3) X(tgt_z, tgt[2], f, 3) X(target_dt, tdt, f, 3) X(target_time, ttime, f, 3) \
-    X(av0, av[0], f, 3) X(av1, av[1], f, 3) X(av2, av[2], f, 3) X(av3, av[3], f, 3) X(av4, av[4], f, 3) X(av5, av[5], f, 3)
+    X(av0, av[0], f, 3) X(av1, av[1], f, 3) X(av2, av[2], f, 3) X(av3, av[3], f, 3) X(av4, av[4], f, 3) X(av5, av[5], f, 3) \
+    X(solver_residual, res, f, 4) \
+    X(aw0, aw[0], f, 5) X(aw1, aw[1], f, 5) X(aw2, aw[2], f, 5) X(aw3, aw[3], f, 5) X(aw4, aw[4], f, 5) X(aw5, aw[5], f, 5) \
+    X(contact_stat, cstat, i, 5)
 
 enum StateField : int {
 #define X(name, member, kind, group) SF_##name,
@@ -77,8 +86,11 @@ constexpr int SF_QPOS0 = SF_q0, SF_QVEL0 = SF_v0;       // 13 qpos rows then 12 
 
 template <int KIND> SO100_HD constexpr bool reach_kind() { return KIND <= 2 || KIND == 6; }    // obs 15, reward env_base_01/06
 template <int KIND> SO100_HD constexpr bool block_kind() { return KIND == 2 || KIND == 6; }    // block_pos / last_block_pos memory
-template <int KIND> SO100_HD constexpr bool uses_group(int g) {
-    return g == 0 || (g == 1 && reach_kind<KIND>()) || (g == 2 && block_kind<KIND>()) || (g == 3 && !reach_kind<KIND>());
+// FL: the kernel's compile-time physics flags (-1 = decided at run time: every row is kept)
+template <int KIND, int FL = -1> SO100_HD constexpr bool uses_group(int g) {
+    return g == 0 || (g == 1 && reach_kind<KIND>()) || (g == 2 && block_kind<KIND>()) || (g == 3 && !reach_kind<KIND>())
+        || (g == 4 && (FL < 0 || (FL & (int)(F_FRICTIONLOSS | F_LIMITS | F_PADS_FLOOR | F_PADS_CUBE)) != 0))
+        || (g == 5 && (FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0));
 }
 template <int KIND> SO100_HD constexpr int obs_dim() { return reach_kind<KIND>() ? 15 : 8; }
 
@@ -226,7 +238,8 @@ template <int KIND> SO100_HD void env_init(EnvState& e) {
 template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const float* start_tab, float* obs) {
     // mj_resetData: qpos = qpos0, everything else (velocities, warm starts, applied forces, time, POSES) zero
 #pragma unroll
-    for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.qc[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; }
+    for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.qc[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; e.aw[i] = 0.0f; }
+    e.res = 0.0f; e.cstat = 0;
     e.cube.pos[0] = e.cube.pos[1] = e.cube.pos[2] = 0.0f;
     e.cube.quat[0] = 1.0f; e.cube.quat[1] = e.cube.quat[2] = e.cube.quat[3] = 0.0f;
     e.ee[0] = e.ee[1] = e.ee[2] = 0.0f; e.wrist_z = 0.0f; e.cx[0] = e.cx[1] = e.cx[2] = 0.0f;
@@ -265,11 +278,20 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
     Arm<float> A;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
+    const bool pads = (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
+    e.res = 0.0f; e.cstat = 0;
 #pragma unroll 1
     for (int s = 0; s < p.frame_skip; s++) {
         cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
-        arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, s == 0, dq);
-        cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
+        if (pads) {
+            int st[3];
+            substep_with_pads<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, e.cube, applied, p.flags, p.solver_iters, p.contact_iters, A, s == 0, dq, &e.res, st);
+            const int n = e.cstat & 255, dr = e.cstat >> 8;
+            e.cstat = (st[0] > n ? st[0] : n) | ((dr + st[2] > 0xFFFF ? 0xFFFF : dr + st[2]) << 8);
+        } else {
+            arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, s == 0, dq, &e.res);
+            cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);
+        }
     }
     e.nsub += p.frame_skip;
     task_poses<float>(A.s, A.c, want_cam, P);      // sin/cos of the angles the last substep STARTED from

