@@ -653,82 +653,80 @@ static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls =
 static int g_dbg_cnewton_trace = 0;
 #endif
 
-// Newton on the primal problem.  x: warm start in, solution out.  L6 / Dinv6: LDL^T factor of the arm's M (for the cheap
-// optimality test g'M^-1 g).  Returns the size of the last step (the solver residual a caller can watch).
+// Newton on the primal problem.  x: warm start in, solution out.  Returns the size of the last Newton step when the
+// iteration budget ran out before the step fell under the tolerance (0 otherwise): the solver residual a caller can watch.
+//
+// One pass over the rows per iteration in the common case: eval<2> gives gradient and Hessian at x, the full Newton step is
+// taken, and the NEXT iteration's eval<2> at x + dx doubles as its acceptance test -- the step stands if the directional
+// derivative there, phi'(1) = g(x + dx).dx, is at most half of |phi'(0)| (phi convex with phi' continuous and piecewise
+// linear: no row changed zone => phi'(1) = 0).  Only when a step overshoots (many rows switching on: an impact) is the exact
+// line search run (safeguarded Newton on phi', one derivative pass per trial).  No cost values are compared anywhere:
+// 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost DIFFERENCE of the size of a Newton decrement is below the
+// round-off of the two costs.
 template <int ND, typename T, class Store>
-SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, const T* L6, const T* Dinv6, int iters, T x[ND]) {
+SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND]) {
     constexpr int NH = ND*(ND + 1)/2;
     const bool f32 = sizeof(T) == 4;
     T last = T(0);
 #if !defined(__HIPCC__)
     g_dbg_cnewton_calls++;
 #endif
+    T g[ND], H[NH];
+    P.template eval<2>(x, g, H);
     for (int it = 0; it < iters; it++) {
-        T g[ND], H[NH], Dinv[ND], dx[ND];
-        // cheap optimality test from the gradient alone: H >= M, so dx'M dx <= g'M^-1 g =: E bounds the Newton step
-        {
-            P.template eval<1>(x, g, H);
-            T t[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) t[i] = g[i];
-            ldl6_solve(L6, Dinv6, t);
-            T E = T(0), xm = T(0);
-#pragma unroll
-            for (int i = 0; i < 6; i++) { E += g[i]*t[i]; xm = tmax(xm, tabs(x[i])); }
-            // arm: M >= armature (0.1) => |dx|^2 <= E / 0.1
-            const T tol = (f32 ? T(0.25e-4) : T(0.25e-11))*(T(1) + T(0.01)*xm);
-            bool small = E < T(so100g::ARMATURE)*tol*tol;
-            if (ND == 12) {
-                const T Ec = (g[6]*g[6] + g[7]*g[7] + g[8]*g[8])*T(1.0/so100g::CUBE_MASS) + (g[9]*g[9] + g[10]*g[10] + g[11]*g[11])*T(1.0/so100g::CUBE_INERTIA);
-                const T tq = f32 ? T(0.25e-4) : T(0.25e-11);
-                small = small && Ec < tq*tq*T(so100g::CUBE_MASS/1.5);
-            }
-            if (small) { last = T(0); break; }
-        }
+        T Dinv[ND], dx[ND];
 #if !defined(__HIPCC__)
         g_dbg_cnewton_iters++;
 #endif
-        P.template eval<2>(x, g, H);
 #pragma unroll
         for (int i = 0; i < ND; i++) dx[i] = -g[i];
         ldln<ND>(H, Dinv);
         ldln_solve<ND>(H, Dinv, dx);
-        T dmax = T(0), xmax = T(0);
+        T dmax = T(0), xmax = T(0), gdx = T(0);
 #pragma unroll
         for (int i = 0; i < ND; i++) {
             const T sc = (ND == 12 && i >= 9) ? T(so100g::CUBE_HALF) : T(1);      // cube angular acceleration measured at the cube's corner
             dmax = tmax(dmax, tabs(dx[i])*sc); xmax = tmax(xmax, tabs(x[i])*sc);
+            gdx += g[i]*dx[i];
         }
-        last = dmax;
 #if !defined(__HIPCC__)
-        if (g_dbg_cnewton_trace) printf("  it %d |g| %.3e dmax %.3e xmax %.3e\n", it, (double)tsqrt(g[0]*g[0]+g[1]*g[1]+g[2]*g[2]+g[3]*g[3]+g[4]*g[4]+g[5]*g[5]), (double)dmax, (double)xmax);
+        if (g_dbg_cnewton_trace) printf("  it %d g.dx %.3e dmax %.3e xmax %.3e\n", it, (double)gdx, (double)dmax, (double)xmax);
 #endif
         const T tol = (f32 ? T(1e-4) : T(1e-11))*(T(1) + T(0.01)*xmax);
-        if (dmax < tol) {
+        if (dmax < tol) {                                     // converged: the step no longer changes the acceleration
 #pragma unroll
             for (int i = 0; i < ND; i++) x[i] += dx[i];
+            last = T(0);
             break;
         }
-        // Line search on phi(alpha) = cost(x + alpha dx) by safeguarded Newton on phi' (continuous, increasing, piecewise linear),
-        // starting with the full step.  No cost values are compared: 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost
-        // DIFFERENCE of the size of the predicted decrease is below the round-off of the two costs.  The outer loop never stops on
-        // the strength of the line search (phi'(1) small against phi'(0) = g.dx says little when g was 1e4 at a contact onset):
-        // only the gradient test at the top of the next iteration, or a step below tolerance, ends it.
-        T gdx = T(0);
+        last = dmax;
+        T xn[ND], gn[ND];
 #pragma unroll
-        for (int i = 0; i < ND; i++) gdx += g[i]*dx[i];
-        T lo = T(0), hi = T(-1), alpha = T(1), d1, d2;          // hi < 0: no upper bracket yet
+        for (int i = 0; i < ND; i++) xn[i] = x[i] + dx[i];
+        P.template eval<2>(xn, gn, H);                        // gradient + Hessian at the trial point: next iteration's, if accepted
+        T d1 = T(0);
+#pragma unroll
+        for (int i = 0; i < ND; i++) d1 += gn[i]*dx[i];
+        if (d1 <= T(0.5)*tabs(gdx)) {
+#pragma unroll
+            for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
+            continue;
+        }
+        // the full step overshot: exact line search in (0, 1) by safeguarded Newton on phi'
+        T lo = T(0), hi = T(1), alpha = T(1), d2;
+        {   // first trial from the secant of phi'(0) = gdx < 0 and phi'(1) = d1 > 0
+            alpha = gdx/(gdx - d1);
+        }
 #pragma unroll 1
-        for (int ls = 0; ls < 12; ls++) {
+        for (int ls = 0; ls < 10; ls++) {
             P.line_deriv(x, dx, alpha, d1, d2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
 #endif
-            if (tabs(d1) <= (f32 ? T(1e-4) : T(1e-10))*tabs(gdx)) break;
+            if (tabs(d1) <= (f32 ? T(1e-3) : T(1e-10))*tabs(gdx)) break;
             if (d1 < T(0)) lo = alpha; else hi = alpha;
             T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
-            const bool inside = an > lo && (hi < T(0) || an < hi);
-            if (!inside) an = hi < T(0) ? T(2)*alpha : T(0.5)*(lo + hi);
+            if (!(an > lo && an < hi)) an = T(0.5)*(lo + hi);
             if (tabs(an - alpha) <= (f32 ? T(1e-4) : T(1e-10))*tabs(alpha)) { alpha = an; break; }
             alpha = an;
         }
@@ -737,6 +735,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, const T* L6, cons
 #endif
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += alpha*dx[i];
+        P.template eval<2>(x, g, H);
     }
     return last;
 }
@@ -762,7 +761,7 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
         T x[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) x[i] = aw[i];
-        res = primal_newton<6>(P, A.M, A.Dinv, iters, x);
+        res = primal_newton<6>(P, iters, x);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[i] = x[i];
     } else {
@@ -772,7 +771,7 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
         for (int i = 0; i < 6; i++) x[i] = aw[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) { x[6 + i] = cube.warm[i] + a0c[i]; x[9 + i] = cube.warm[3 + i]; }
-        res = primal_newton<12>(P, A.M, A.Dinv, iters, x);
+        res = primal_newton<12>(P, iters, x);
 #pragma unroll
         for (int i = 0; i < 6; i++) acc[i] = x[i];
         if (xcube_out) {                                      // multi-wave kernels: the wave that owns the cube integrates it

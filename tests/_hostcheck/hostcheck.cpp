@@ -119,6 +119,7 @@ void hc_env_step(void* e, int kind, unsigned flags, int iters, int citers, int m
     SimParams p{}; p.n = 1; p.flags = flags; p.solver_iters = iters; p.contact_iters = citers; p.frame_skip = 16; p.max_episode_steps = max_steps;
     KSWITCH(kind, env_stp, (EnvState*)e, p, a, inject, obs, tobs, rew, done, trunc);
 }
+void hc_env_stats(void* ev, double* out2) { EnvState* e = (EnvState*)ev; out2[0] = e->cstat; out2[1] = e->res; }
 void hc_env_qpos(void* ev, double* qpos13, double* qvel12) {
     EnvState* e = (EnvState*)ev;
     for (int i = 0; i < 6; i++) { qpos13[i] = e->q[i]; qvel12[i] = e->v[i]; qvel12[6+i] = e->cube.vel[i]; }

@@ -513,7 +513,7 @@ def test_c_abi_from_plain_cpp(tmp_path):
     out = subprocess.check_output([exe, str(n), str(steps)], text=True)
     m = re.search(r"obs_checksum (\S+)\s+reward_sum (\S+)", out)
     assert m, out
-    sim = _sim(1, n, flags=REF, solver_iters=3, contact_iters=4, seed=42)
+    sim = _sim(1, n, flags=lib.F_REFERENCE, solver_iters=3, contact_iters=4, seed=42)     # SO100_F_REFERENCE in abi_demo.cpp
     sim.reset()
     idx = np.arange(6 * n, dtype=np.uint64)
     a = ((idx * np.uint64(2654435761)) % np.uint64(2001)).astype(np.float32) / np.float32(1000.0) - np.float32(1.0)   # as abi_demo.cpp (64-bit product)
