@@ -497,23 +497,26 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll 1
         for (int s = 0; s < cs.n; s++) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
-            const T n[3] = { cs.get(s, C_NX), cs.get(s, C_NY), cs.get(s, C_NZ) };
-            T t1[3], t2[3]; contact_frame(n, t1, t2);
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
             const int kind = (int)cs.get(s, C_KIND);
-            const bool on5 = kind == 2 || kind == 4, arm_side = kind != 0, cube_side = kind == 0 || kind >= 3;
-            const T sgn = kind >= 3 ? T(-1) : T(1);             // the arm link is geom1 in pad/cube pairs, geom2 in pad/floor pairs
+            // ND == 6 (arm alone): every record is a pad/floor contact, whose frame is made of world axes (mju_makeFrame of +z:
+            // n = e_z, t1 = e_y, t2 = -e_x): projections on the frame are component picks
+            T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
+            if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
+            const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube pairs, geom2 in pad/floor pairs
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) };
             if (arm_side) { T ap[3]; point_motion(on5 ? S5 : S4, p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
             if (ND == 12 && cube_side) { T ac[3]; cube_point_motion(Rc, cpos, x + 6, p, ac); w[0] += ac[0]; w[1] += ac[1]; w[2] += ac[2]; }
-            const T jn = dot(n, w) + kd, j1 = dot(t1, w), j2 = dot(t2, w);
+            const T jn = (ND == 6 ? w[2] : dot(n, w)) + kd, j1 = ND == 6 ? w[1] : dot(t1, w), j2 = ND == 6 ? -w[0] : dot(t2, w);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 };        // edges n +- mu t1, n +- mu t2 (mu = 1)
             T m_[4];
 #pragma unroll
             for (int e = 0; e < 4; e++) { m_[e] = jar[e] < T(0) ? jar[e] : T(0); cost += T(0.5)*D*m_[e]*m_[e]; }
             if (MODE >= 1) {
                 const T cn = D*(m_[0] + m_[1] + m_[2] + m_[3]), c1 = D*(m_[0] - m_[1]), c2 = D*(m_[2] - m_[3]);
-                const T Fv[3] = { cn*n[0] + c1*t1[0] + c2*t2[0], cn*n[1] + c1*t1[1] + c2*t2[1], cn*n[2] + c1*t1[2] + c2*t2[2] };
+                T Fv[3] = { -c2, c1, cn };
+                if (ND == 12) { Fv[0] = cn*n[0] + c1*t1[0] + c2*t2[0]; Fv[1] = cn*n[1] + c1*t1[1] + c2*t2[1]; Fv[2] = cn*n[2] + c1*t1[2] + c2*t2[2]; }
                 if (arm_side) {
                     T tq[3]; cross(p, Fv, tq);
                     if (on5) { F5[0] += sgn*Fv[0]; F5[1] += sgn*Fv[1]; F5[2] += sgn*Fv[2]; T5[0] += sgn*tq[0]; T5[1] += sgn*tq[1]; T5[2] += sgn*tq[2]; }
@@ -536,7 +539,8 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                     const bool moves = arm_side && (i < 5 || on5);
                     const T r[3] = { p[0] - W.o[i][0], p[1] - W.o[i][1], p[2] - W.o[i][2] };
                     T col[3]; cross(W.z[i], r, col);
-                    cn_[i] = moves ? sgn*dot(n, col) : T(0); c1_[i] = moves ? sgn*dot(t1, col) : T(0); c2_[i] = moves ? sgn*dot(t2, col) : T(0);
+                    if (ND == 6) { cn_[i] = moves ? col[2] : T(0); c1_[i] = moves ? col[1] : T(0); c2_[i] = moves ? -col[0] : T(0); }
+                    else { cn_[i] = moves ? sgn*dot(n, col) : T(0); c1_[i] = moves ? sgn*dot(t1, col) : T(0); c2_[i] = moves ? sgn*dot(t2, col) : T(0); }
                 }
                 if (ND == 12) {
                     const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
@@ -623,12 +627,12 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll 1
         for (int s = 0; s < cs.n; s++) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
-            const T n[3] = { cs.get(s, C_NX), cs.get(s, C_NY), cs.get(s, C_NZ) };
-            T t1[3], t2[3]; contact_frame(n, t1, t2);
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
             const int kind = (int)cs.get(s, C_KIND);
-            const bool on5 = kind == 2 || kind == 4, arm_side = kind != 0, cube_side = kind == 0 || kind >= 3;
-            const T sgn = kind >= 3 ? T(-1) : T(1);
+            T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
+            if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
+            const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) }, wd[3] = { T(0), T(0), T(0) };
             if (arm_side) {
                 T ap[3], ad[3]; point_motion(on5 ? S5 : S4, p, ap); point_motion(on5 ? D5 : D4, p, ad);
@@ -640,7 +644,8 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll
                 for (int k = 0; k < 3; k++) { w[k] += ac[k]; wd[k] += ad[k]; }
             }
-            const T jn = dot(n, w) + kd, j1 = dot(t1, w), j2 = dot(t2, w), dn = dot(n, wd), e1 = dot(t1, wd), e2 = dot(t2, wd);
+            const T jn = (ND == 6 ? w[2] : dot(n, w)) + kd, j1 = ND == 6 ? w[1] : dot(t1, w), j2 = ND == 6 ? -w[0] : dot(t2, w);
+            const T dn = ND == 6 ? wd[2] : dot(n, wd), e1 = ND == 6 ? wd[1] : dot(t1, wd), e2 = ND == 6 ? -wd[0] : dot(t2, wd);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 }, jd[4] = { dn + e1, dn - e1, dn + e2, dn - e2 };
 #pragma unroll
             for (int e = 0; e < 4; e++) if (jar[e] < T(0)) { d1 += D*jar[e]*jd[e]; d2 += D*jd[e]*jd[e]; }
@@ -663,6 +668,19 @@ static int g_dbg_cnewton_trace = 0;
 // line search run (safeguarded Newton on phi', one derivative pass per trial).  No cost values are compared anywhere:
 // 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost DIFFERENCE of the size of a Newton decrement is below the
 // round-off of the two costs.
+// Stopping in fp32.  The pad rows are stiff (1/R = 3e3 against M ~ 0.1): a row's force is D * jar with jar = J.x + b a small
+// difference of O(10) terms, so forces carry a relative round-off of ~3e-4 and the gradient never falls below that floor.  The
+// iteration therefore also ends when a step of at most 1e-3 relative size brings no further progress in the scaled gradient
+// norm E = g'diag(M)^-1 g (quadratic convergence would have divided it by far more than 4): converged to working precision.
+template <int ND, typename T> SO100_HD T grad_merit(const T g[ND]) {
+    T E = T(0);
+#pragma unroll
+    for (int i = 0; i < 6; i++) E += g[i]*g[i];
+    E *= T(1.0/so100g::ARMATURE);
+    if (ND == 12) E += (g[6]*g[6] + g[7]*g[7] + g[8]*g[8])*T(1.0/so100g::CUBE_MASS) + (g[9]*g[9] + g[10]*g[10] + g[11]*g[11])*T(1.0/so100g::CUBE_INERTIA);
+    return E;
+}
+
 template <int ND, typename T, class Store>
 SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND]) {
     constexpr int NH = ND*(ND + 1)/2;
@@ -673,6 +691,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #endif
     T g[ND], H[NH];
     P.template eval<2>(x, g, H);
+    T E0 = grad_merit<ND>(g);
     for (int it = 0; it < iters; it++) {
         T Dinv[ND], dx[ND];
 #if !defined(__HIPCC__)
@@ -690,7 +709,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
             gdx += g[i]*dx[i];
         }
 #if !defined(__HIPCC__)
-        if (g_dbg_cnewton_trace) printf("  it %d g.dx %.3e dmax %.3e xmax %.3e\n", it, (double)gdx, (double)dmax, (double)xmax);
+        if (g_dbg_cnewton_trace) printf("  it %d E %.3e g.dx %.3e dmax %.3e xmax %.3e\n", it, (double)E0, (double)gdx, (double)dmax, (double)xmax);
 #endif
         const T tol = (f32 ? T(1e-4) : T(1e-11))*(T(1) + T(0.01)*xmax);
         if (dmax < tol) {                                     // converged: the step no longer changes the acceleration
@@ -704,30 +723,39 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll
         for (int i = 0; i < ND; i++) xn[i] = x[i] + dx[i];
         P.template eval<2>(xn, gn, H);                        // gradient + Hessian at the trial point: next iteration's, if accepted
+        const T E1 = grad_merit<ND>(gn);
         T d1 = T(0);
 #pragma unroll
         for (int i = 0; i < ND; i++) d1 += gn[i]*dx[i];
-        if (d1 <= T(0.5)*tabs(gdx)) {
+        const bool progress = E1 <= T(0.25)*E0;
+        if (!progress && dmax < (f32 ? T(1e-3) : T(1e-10))*(T(1) + xmax)) {   // working precision reached (see above)
+            if (E1 <= E0) {
+#pragma unroll
+                for (int i = 0; i < ND; i++) x[i] = xn[i];
+            }
+            last = T(0);
+            break;
+        }
+        if (progress || d1 <= T(0.5)*tabs(gdx)) {
 #pragma unroll
             for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
+            E0 = E1;
             continue;
         }
-        // the full step overshot: exact line search in (0, 1) by safeguarded Newton on phi'
-        T lo = T(0), hi = T(1), alpha = T(1), d2;
-        {   // first trial from the secant of phi'(0) = gdx < 0 and phi'(1) = d1 > 0
-            alpha = gdx/(gdx - d1);
-        }
+        // the full step overshot: exact line search in (0, 1) by safeguarded Newton on phi', first trial from the secant of
+        // phi'(0) = g.dx < 0 and phi'(1) = d1 > 0
+        T lo = T(0), hi = T(1), alpha = gdx/(gdx - d1), d2;
 #pragma unroll 1
-        for (int ls = 0; ls < 10; ls++) {
+        for (int ls = 0; ls < 6; ls++) {
             P.line_deriv(x, dx, alpha, d1, d2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
 #endif
-            if (tabs(d1) <= (f32 ? T(1e-3) : T(1e-10))*tabs(gdx)) break;
+            if (tabs(d1) <= (f32 ? T(1e-2) : T(1e-10))*tabs(gdx)) break;
             if (d1 < T(0)) lo = alpha; else hi = alpha;
             T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
             if (!(an > lo && an < hi)) an = T(0.5)*(lo + hi);
-            if (tabs(an - alpha) <= (f32 ? T(1e-4) : T(1e-10))*tabs(alpha)) { alpha = an; break; }
+            if (tabs(an - alpha) <= (f32 ? T(1e-3) : T(1e-10))*tabs(alpha)) { alpha = an; break; }
             alpha = an;
         }
 #if !defined(__HIPCC__)
@@ -736,6 +764,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += alpha*dx[i];
         P.template eval<2>(x, g, H);
+        E0 = grad_merit<ND>(g);
     }
     return last;
 }

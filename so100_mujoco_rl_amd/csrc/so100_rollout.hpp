@@ -407,8 +407,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env = blockIdx.x*64 + lane;
-    const bool live = env < p.n;
+    const int env = blockIdx.x*p.epw + lane;                       // p.epw lanes of each wave own an env (64, or fewer to spread a small batch over all CUs)
+    const bool live = lane < p.epw && env < p.n;
     const int tower = wave >> 1, rt = wave & 1;
     const int lj = lane & 31, lh = lane >> 5;
     // ---- once per launch: weight fragments -> registers, head weights -> LDS, env state -> registers, obs -> LDS
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     }
     EnvState e;
     if (wave == 0) {
-        if (live) load_env_state<KIND, FL>(state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
+        if (live) load_env_state<KIND, FL>(state, p.n, env, e); else idle_lane_state(e);
 #pragma unroll
         for (int k = 0; k < ODP; k++) oxt[lane][k] = (live && k < OD) ? ra.obs_in[(size_t)env*OD + k] : 0.0f;
     }
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
                 const float ls = hd[7*64 + 6 + a];
                 const float raw = __builtin_fmaf(__builtin_expf(ls), eps[a], mean[a]);
                 lp += -0.5f*eps[a]*eps[a] - ls - 0.9189385332046727f;
-                act[a] = tclamp(raw, -1.0f, 1.0f);
+                act[a] = live ? tclamp(raw, -1.0f, 1.0f) : 0.0f;
                 if (live) row[OD + a] = raw;
             }
             if (live) {

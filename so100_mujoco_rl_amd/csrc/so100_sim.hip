@@ -116,13 +116,13 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env = blockIdx.x*64 + lane;
-    const bool live = env < p.n;
+    const int env = blockIdx.x*p.epw + lane;
+    const bool live = lane < p.epw && env < p.n;
     constexpr int OD = obs_dim<KIND>();
     EnvState e; StepCtx ctx{}; float u[8] = {}; float cstale[3] = {};
     const float* inj = (io.inject && live) ? io.inject + (size_t)env*SO100_NINJECT : nullptr;
     if (wave == 0) {
-        if (live) load_env_state<KIND, FL>(io.state, p.n, env, e); else { e = EnvState{}; e.cube.quat[0] = 1.0f; }
+        if (live) load_env_state<KIND, FL>(io.state, p.n, env, e); else idle_lane_state(e);
         float a[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) a[i] = live ? io.act[(size_t)env*6 + i] : 0.0f;
@@ -227,7 +227,7 @@ constexpr int MW_MAX_ENVS = 16384;   // up to here the 4-wave step kernel wins (
 
 template <int KIND> int launch_step(so100_sim* s, const StepPtrs& io, hipStream_t st) {
     const bool mw = s->prm.n <= MW_MAX_ENVS;
-    const dim3 g = grid_for(s->prm.n), b(mw ? 256 : WG);
+    const dim3 g = mw ? dim3((unsigned)((s->prm.n + s->prm.epw - 1)/s->prm.epw)) : grid_for(s->prm.n), b(mw ? 256 : WG);
 #define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, s->prm, io); \
                              else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, s->prm, io); } while (0)
     switch (s->prm.flags) {
@@ -302,6 +302,18 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     s->prm.max_episode_steps = cfg->max_episode_steps;
     s->prm.seed_lo = (uint32_t)cfg->seed; s->prm.seed_hi = (uint32_t)(cfg->seed >> 32);
     s->prm.env_id_offset = cfg->env_id_offset;
+    {   // envs per workgroup of the multi-wave kernels.  Their step time is set by the slowest lane of a wave (a cube in a contact
+        // transient, a pad hitting the floor: data-dependent Newton iterations), so a batch that leaves CUs idle is spread thinner:
+        // 16 or 32 envs per 4-wave workgroup while that still fits one workgroup per CU.  Variants without a data-dependent solve
+        // (cube pinned) gain nothing and keep 64.
+        hipDeviceProp_t prop;
+        int cus = 256;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        int epw = 64;
+        if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
+            while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
+        s->prm.epw = epw;
+    }
     const size_t bytes = (size_t)SF_COUNT*(size_t)cfg->num_envs*sizeof(float);
     if (hipMalloc(&s->state, bytes) != hipSuccess) { delete s; return fail(SO100_E_NOMEM, "so100_create: hipMalloc of %s%ld bytes failed", "", (long)bytes); }
     float tab[36*6];
@@ -377,7 +389,7 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
     if (!g.ok) return fail(SO100_E_NODEVICE, "so100_rollout: cannot select the device%s");
     PolicyWeights pw; memcpy(&pw, w, sizeof pw);
     RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev; ra.tobs_chunk = io->terminal_obs_chunk_dev;
-    const dim3 grid((unsigned)((s->prm.n + 63)/64));
+    const dim3 grid((unsigned)((s->prm.n + s->prm.epw - 1)/s->prm.epw));
     hipStream_t st = (hipStream_t)stream;
 #define SO100_RL(KIND, FLV, NW) hipLaunchKernelGGL((so100_rollout_fused<KIND, FLV, NW>), grid, dim3(64*NW), 0, st, s->prm, s->state, s->start_tab, \
         io->obs_dev, io->rew_dev, io->done_dev, io->trunc_dev, io->terminal_obs_dev, io->ep_return_dev, io->ep_length_dev, pw, ra)

@@ -20,7 +20,12 @@ struct SimParams {
     uint32_t flags;
     int32_t  solver_iters, contact_iters, frame_skip, max_episode_steps;
     uint32_t seed_lo, seed_hi, env_id_offset;
+    int32_t  epw;                // envs per workgroup of the multi-wave kernels (64, 32 or 16 lanes of each wave in use)
 };
+
+// State of a lane that owns no env (tail of the last workgroup, or lanes >= epw): it must not make its wave wait.  An all-zero
+// state would: the cube sits 1 cm inside the floor (a full Newton solve every substep) and the stretched arm's pads touch it.
+// Arm folded up 28 cm above the floor, cube floating (anti-gravity), everything at rest; its action is forced to zero.
 
 // ---- per-env persistent state ---------------------------------------------------------------------
 // bits of EnvState::bits
@@ -47,6 +52,15 @@ struct EnvState {
     float aw[6];                // arm qacc of the previous substep: warm start of the pad-contact Newton (so100_contact.hpp)
     int   cstat;                // pad contacts: most contacts in a substep of the last env step | (dropped over the budget) << 8
 };
+
+SO100_HD void idle_lane_state(EnvState& e) {
+    e = EnvState{};
+    const float q[6] = { 0.0f, -1.9f, 1.6f, 0.3f, 1.5708f, 0.1f };
+#pragma unroll
+    for (int i = 0; i < 6; i++) e.q[i] = q[i];
+    e.cube.pos[0] = 0.3f; e.cube.pos[1] = 0.3f; e.cube.pos[2] = 0.5f; e.cube.quat[0] = 1.0f;
+    e.bits = B_ANTIGRAV;
+}
 
 // The [field][N] state matrix.  X(name, member, kind, group): kind f = float, i = int32;
 // group 0 = all env kinds, 1 = Env01/02/06 (reach family), 2 = Env02/06 (block memory), 3 = Env03-05 (look-at family),
