@@ -657,6 +657,14 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0;     // host-only instrumentation
 static int g_dbg_cnewton_trace = 0;
 #endif
+#if defined(SO100_CONTACT_STATS) && defined(__HIPCC__)
+__device__ unsigned long long so100_cstats[8];          // calls, iterations, line-search passes, evals, capped calls (tools/micro/contact_bench.hip)
+#endif
+#if defined(SO100_CONTACT_STATS) && defined(__HIP_DEVICE_COMPILE__)
+#define SO100_CSTAT(i) atomicAdd(&so100_cstats[i], 1ull)
+#else
+#define SO100_CSTAT(i) ((void)0)
+#endif
 
 // Newton on the primal problem.  x: warm start in, solution out.  Returns the size of the last Newton step when the
 // iteration budget ran out before the step fell under the tolerance (0 otherwise): the solver residual a caller can watch.
@@ -691,9 +699,12 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #endif
     T g[ND], H[NH];
     P.template eval<2>(x, g, H);
+    SO100_CSTAT(0); SO100_CSTAT(3);
     T E0 = grad_merit<ND>(g);
     for (int it = 0; it < iters; it++) {
         T Dinv[ND], dx[ND];
+        SO100_CSTAT(1);
+        if (it == iters - 1) SO100_CSTAT(4);
 #if !defined(__HIPCC__)
         g_dbg_cnewton_iters++;
 #endif
@@ -723,6 +734,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll
         for (int i = 0; i < ND; i++) xn[i] = x[i] + dx[i];
         P.template eval<2>(xn, gn, H);                        // gradient + Hessian at the trial point: next iteration's, if accepted
+        SO100_CSTAT(3);
         const T E1 = grad_merit<ND>(gn);
         T d1 = T(0);
 #pragma unroll
@@ -748,6 +760,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll 1
         for (int ls = 0; ls < 6; ls++) {
             P.line_deriv(x, dx, alpha, d1, d2);
+            SO100_CSTAT(2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
 #endif
@@ -764,6 +777,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += alpha*dx[i];
         P.template eval<2>(x, g, H);
+        SO100_CSTAT(3);
         E0 = grad_merit<ND>(g);
     }
     return last;

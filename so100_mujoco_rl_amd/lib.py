@@ -71,7 +71,7 @@ EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so10
 
 def build(verbose=False):
     """Compile libso100sim.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    out = subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    out = subprocess.run(["make", "-j7", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
     if out.returncode != 0:
         raise So100Error("building libso100sim.so failed:\n" + out.stdout[-4000:] + out.stderr[-4000:])
     if verbose:
