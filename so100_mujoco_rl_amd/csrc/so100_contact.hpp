@@ -92,6 +92,13 @@ template <typename T> SO100_HD void point_motion(const Spatial<T>& S, const T p[
     T t[3]; cross(S.a, p, t);
     out[0] = t[0] + S.b[0]; out[1] = t[1] + S.b[1]; out[2] = t[2] + S.b[2];
 }
+// link 5's or link 4's, selected per lane BY VALUE (a reference select between two register structs would send both to memory)
+template <typename T> SO100_HD Spatial<T> pick_spatial(bool on5, const Spatial<T>& S4, const Spatial<T>& S5) {
+    Spatial<T> S;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { S.a[k] = on5 ? S5.a[k] : S4.a[k]; S.b[k] = on5 ? S5.b[k] : S4.b[k]; }
+    return S;
+}
 
 // ---- contact parameters ------------------------------------------------------------------------------------------------
 // impedance d(r) of the pad-involved pairs: solimp (0.9999, 0.975, 0.0055, 0.5, 2) after mixing + clamp (so100_model_gen.h)
@@ -349,14 +356,18 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
 #pragma unroll 1
         for (int g = 0; g < so100g::NPAD; g++) {
             const bool l5 = so100g::PAD_LINK[g] == 5;
-            const T* R = l5 ? W.R5 : W.R4; const T* o = l5 ? W.o[5] : W.o[4];
+            T R[9], o[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) R[k] = l5 ? W.R5[k] : W.R4[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) o[k] = l5 ? W.o[5][k] : W.o[4][k];
             const T pp[3] = { T(so100g::PAD_POS[g][0]), T(so100g::PAD_POS[g][1]), T(so100g::PAD_POS[g][2]) };
             const T h[3] = { T(so100g::PAD_SIZE[g][0]), T(so100g::PAD_SIZE[g][1]), T(so100g::PAD_SIZE[g][2]) };
             const T c[3] = { o[0] + R[0]*pp[0] + R[1]*pp[1] + R[2]*pp[2], o[1] + R[3]*pp[0] + R[4]*pp[1] + R[5]*pp[2], o[2] + R[6]*pp[0] + R[7]*pp[1] + R[8]*pp[2] };
             if (pass == 0) {
                 if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) {
                     plane_box<T>(c, R, h, [&](const T* p, T dist) {
-                        T vr[3]; point_motion(l5 ? V5 : V4, p, vr);
+                        T vr[3]; point_motion(pick_spatial(l5, V4, V5), p, vr);
                         contact_add(cs, l5 ? 2 : 1, p, nz, dist, vr);
                     });
                 }
@@ -368,7 +379,7 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
                     const int s0 = cs.n;
                     T nrm[3];
                     const int k = box_box<T>(c, R, h, cube.pos, Rc, hc, nrm, [&](const T* p, T dist) {
-                        T va[3], vc[3]; point_motion(l5 ? V5 : V4, p, va); cube_point_motion(Rc, cube.pos, cube.vel, p, vc);
+                        T va[3], vc[3]; point_motion(pick_spatial(l5, V4, V5), p, va); cube_point_motion(Rc, cube.pos, cube.vel, p, vc);
                         const T vr[3] = { vc[0] - va[0], vc[1] - va[1], vc[2] - va[2] };
                         contact_add(cs, l5 ? 4 : 3, p, nz, dist, vr);
                     });
@@ -506,7 +517,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
             const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube pairs, geom2 in pad/floor pairs
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) };
-            if (arm_side) { T ap[3]; point_motion(on5 ? S5 : S4, p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
+            if (arm_side) { T ap[3]; point_motion(pick_spatial(on5, S4, S5), p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
             if (ND == 12 && cube_side) { T ac[3]; cube_point_motion(Rc, cpos, x + 6, p, ac); w[0] += ac[0]; w[1] += ac[1]; w[2] += ac[2]; }
             const T jn = (ND == 6 ? w[2] : dot(n, w)) + kd, j1 = ND == 6 ? w[1] : dot(t1, w), j2 = ND == 6 ? -w[0] : dot(t2, w);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 };        // edges n +- mu t1, n +- mu t2 (mu = 1)
@@ -545,16 +556,14 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 if (ND == 12) {
                     const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
                     const T on = cube_side ? T(1) : T(0);
-                    const T* dirs[3] = { n, t1, t2 }; T* outs[3] = { cn_, c1_, c2_ };
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        const T* d = dirs[a]; T* o = outs[a];
+                    auto cube_cols = [&](const T d[3], T o[ND]) {
                         T tw[3]; cross(r, d, tw);
                         o[6] = on*d[0]; o[7] = on*d[1]; o[8] = on*d[2];
                         o[9]  = on*(Rc[0]*tw[0] + Rc[3]*tw[1] + Rc[6]*tw[2]);
                         o[10] = on*(Rc[1]*tw[0] + Rc[4]*tw[1] + Rc[7]*tw[2]);
                         o[11] = on*(Rc[2]*tw[0] + Rc[5]*tw[1] + Rc[8]*tw[2]);
-                    }
+                    };
+                    cube_cols(n, cn_); cube_cols(t1, c1_); cube_cols(t2, c2_);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -635,7 +644,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) }, wd[3] = { T(0), T(0), T(0) };
             if (arm_side) {
-                T ap[3], ad[3]; point_motion(on5 ? S5 : S4, p, ap); point_motion(on5 ? D5 : D4, p, ad);
+                T ap[3], ad[3]; point_motion(pick_spatial(on5, S4, S5), p, ap); point_motion(pick_spatial(on5, D4, D5), p, ad);
 #pragma unroll
                 for (int k = 0; k < 3; k++) { w[k] += sgn*ap[k]; wd[k] += sgn*ad[k]; }
             }
@@ -783,61 +792,62 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
     return last;
 }
 
+// ---- the constraint solve of a lane with pad contacts ----------------------------------------------------------------------
+// tau: the arm's smooth force (actuation - bias), Marm: its mass matrix (packed lower, unfactored), r: row constants
+// (arm_row_consts / arm_rows).  acc: warm start in (previous substep's arm acceleration), solution out.  coupled: solve the
+// cube together with the arm (cs then holds its floor contacts too); cwarm = the cube's warm start in so100_cube.hpp's
+// convention (qacc - qacc_smooth), xcube = its acceleration out.  Returns the solver residual (0 when converged).
+template <typename T, class Store>
+SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], const WorldFK<T>& W, const Store& cs, bool coupled,
+                         const T cpos[3], const T cwarm[6], const T Rc[9], const T applied[3], int iters, T acc[6], T xcube[6]) {
+    const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
+    T res;
+    if (!coupled) {
+        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c };
+        res = primal_newton<6>(P, iters, acc);
+    } else {
+        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c };
+        T x[12];
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { x[6 + i] = cwarm[i] + a0c[i]; x[9 + i] = cwarm[3 + i]; }
+        res = primal_newton<12>(P, iters, x);
+#pragma unroll
+        for (int i = 0; i < 6; i++) { acc[i] = x[i]; xcube[i] = x[6 + i]; }
+    }
+    return res;
+}
+
 // ---- one arm (+ cube) substep with pad contacts, single lane ----------------------------------------------------------
 // Called INSTEAD of arm_solve_integrate (+ cube_finish) by lanes that have pad contacts.  A holds the factorised mass matrix
 // (arm_factor) and the bias force.  aw: the arm's qacc warm start (previous substep's acceleration), updated.
-// coupled: solve the cube together with the arm (cs then holds its floor contacts too) and integrate it here.
+// coupled: the cube is solved with the arm and integrated here.
 template <typename T, class Store>
 SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], unsigned flags, int iters,
                                       Arm<T>& A, const WorldFK<T>& W, const Store& cs, bool coupled, Cube<T>& cube, const T Rc[9],
-                                      const T applied[3], T dq[6], T* residual, T* xcube_out = nullptr) {
-    T tau[6], acc[6];
+                                      const T applied[3], T dq[6], T* residual) {
+    T tau[6], acc[6], xcube[6];
     arm_tau(q, v, ctrl, A, tau);
     ArmRows<T> r;
-    arm_rows(q, v, tau, ff, fl, flags, A, r);
+    arm_row_consts(q, v, flags, r);
     T Marm[21];
     ldl6_reconstruct(A.M, Marm);
-    T res;
-    const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
-    if (!coupled) {
-        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cube.pos, a0c };
-        T x[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = aw[i];
-        res = primal_newton<6>(P, iters, x);
+    for (int i = 0; i < 6; i++) acc[i] = aw[i];
+    const T res = contact_solve(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube);
+    if (coupled) {
+        // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
+        const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
 #pragma unroll
-        for (int i = 0; i < 6; i++) acc[i] = x[i];
-    } else {
-        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cube.pos, a0c };
-        T x[12];
-#pragma unroll
-        for (int i = 0; i < 6; i++) x[i] = aw[i];
-#pragma unroll
-        for (int i = 0; i < 3; i++) { x[6 + i] = cube.warm[i] + a0c[i]; x[9 + i] = cube.warm[3 + i]; }
-        res = primal_newton<12>(P, iters, x);
-#pragma unroll
-        for (int i = 0; i < 6; i++) acc[i] = x[i];
-        if (xcube_out) {                                      // multi-wave kernels: the wave that owns the cube integrates it
-#pragma unroll
-            for (int i = 0; i < 6; i++) xcube_out[i] = x[6 + i];
-        } else {
-            // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
-#pragma unroll
-            for (int i = 0; i < 3; i++) { cube.warm[i] = x[6 + i] - a0c[i]; cube.warm[3 + i] = x[9 + i]; }
-            const T al[3] = { x[6], x[7], x[8] }, aa[3] = { x[9], x[10], x[11] };
-            cube_integrate(cube, al, aa);
-        }
+        for (int i = 0; i < 3; i++) { cube.warm[i] = xcube[i] - a0c[i]; cube.warm[3 + i] = xcube[3 + i]; }
+        const T al[3] = { xcube[0], xcube[1], xcube[2] }, aa[3] = { xcube[3], xcube[4], xcube[5] };
+        cube_integrate(cube, al, aa);
     }
     if (residual) *residual = tmax(*residual, res);
-    // row forces of the solution -> the block PGS's warm-start memory (a lane may be back on that path next substep)
+    arm_row_forces(r, acc, ff, fl);          // the block PGS's warm-start memory (a lane may be back on that path next substep)
 #pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const T F = r.fmax_[i], R = r.Rf[i], jar = acc[i] + r.cfv[i];
-        ff[i] = F > T(0) ? tclamp(-jar*trcp(R), -F, F) : T(0);
-        const T jl = r.sg[i]*acc[i] + r.clv[i];
-        fl[i] = (r.sg[i] != T(0) && jl < T(0)) ? -jl*trcp(r.Rl[i]) : T(0);
-        aw[i] = acc[i];
-    }
+    for (int i = 0; i < 6; i++) aw[i] = acc[i];
     arm_integrate(q, v, qc, acc, dq);
 }
 

@@ -99,12 +99,13 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
 // throughput kernel for large batches.
 template <int KIND, int FL>
 __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
-    __shared__ float xq[18][64];
+    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
+    __shared__ float xq[PADS ? 24 : 18][64];
     __shared__ float xc[24][64];
     __shared__ float xb[6][64];
-    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
     __shared__ float cbuf[PADS ? MAXC*CF*64 : 1];                 // pad contact records [record][field][lane]
-    __shared__ float xa[PADS ? 8 : 1][64];
+    __shared__ float xa[PADS ? 14 : 1][64];
+    __shared__ float xk[PADS ? 12 : 1][64];
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -123,7 +124,8 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
         env_step_pre<KIND>(e, a, u, p, ctx);
     }
     Arm<float> A; Prof prof_;
-    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, cbuf, xa, prof_, [](int) {});
+    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk };
+    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [](int) {});
     if (wave != 0 || !live) return;
     e.nsub += p.frame_skip;
     TaskPoses<float> P;

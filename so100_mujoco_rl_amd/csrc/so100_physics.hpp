@@ -512,6 +512,38 @@ SO100_HD void arm_rows(const T q[6], const T v[6], const T tau[6], T ff[6], T fl
     }
 }
 
+// the rows' constants alone (what a primal solve needs: no a0, no warm-start clamping)
+template <typename T>
+SO100_HD void arm_row_consts(const T q[6], const T v[6], unsigned flags, ArmRows<T>& r) {
+    const T Bd = T(so100g::SOLREF_B), Kd = T(so100g::SOLREF_K);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        r.Rf[i] = T((1.0 - so100g::SOLIMP_D0)/so100g::SOLIMP_D0 * so100g::DOF_INVWEIGHT0[i]);
+        r.cfv[i] = Bd*v[i];
+        r.fmax_[i] = (flags & F_FRICTIONLOSS) != 0u ? T(so100g::FRICTIONLOSS) : T(0);
+        const T dlo = q[i] - T(so100g::JNT_RANGE[i][0]), dhi = T(so100g::JNT_RANGE[i][1]) - q[i];
+        const bool lo = dlo < T(0), hi = dhi < T(0);
+        const bool act = (flags & F_LIMITS) != 0u && (lo || hi);
+        const T dist = lo ? dlo : dhi;
+        const T sg = lo ? T(1) : T(-1);
+        const T imp = impedance(tabs(dist));
+        r.Rl[i] = (T(1) - imp)*trcp(imp) * T(so100g::DOF_INVWEIGHT0[i]);
+        r.clv[i] = Bd*sg*v[i] + Kd*imp*dist;
+        r.sg[i] = act ? sg : T(0);
+    }
+}
+// friction-loss / limit row forces that go with a given acceleration (the block PGS's warm-start memory after a primal solve)
+template <typename T>
+SO100_HD void arm_row_forces(const ArmRows<T>& r, const T acc[6], T ff[6], T fl[6]) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const T F = r.fmax_[i], R = r.Rf[i], jar = acc[i] + r.cfv[i];
+        ff[i] = F > T(0) ? tclamp(-jar*trcp(R), -F, F) : T(0);
+        const T jl = r.sg[i]*acc[i] + r.clv[i];
+        fl[i] = (r.sg[i] != T(0) && jl < T(0)) ? -jl*trcp(r.Rl[i]) : T(0);
+    }
+}
+
 template <typename T>
 SO100_HD void arm_pgs(T ff[6], T fl[6], int iters, const Arm<T>& A, const ArmRows<T>& r, T acc[6], T& residual) {
     const T* Minv = A.Minv;

@@ -59,17 +59,24 @@ struct Prof {
 // On return (wave 0): e.q/v/qc/ff/fl/cube updated, A.s / A.c = sin/cos the LAST substep started from, cstale = the
 // cube position it started from (Q1).
 // ---------------------------------------------------------------------------------------------------------------
-// With the finger-pad contact flags (PADS): wave 3 -- idle otherwise -- runs the world-frame kinematics and the narrowphase
-// (pad/floor, pad/cube) of the substep concurrently with RNEA / CRBA and leaves the contact records in LDS (cbuf, [record]
-// [field][lane]); after the mid-substep barrier wave 0 solves lanes that have contacts in the primal (so100_contact.hpp) and
-// the others with the block PGS as before.  A lane whose pad touches the cube solves arm + cube together on wave 0 and hands
-// the cube's acceleration to wave 2 (which owns the cube state) through LDS: one more barrier per substep, only in kernels
-// compiled with F_PADS_CUBE.  xa: [8][64] floats -- rows 0-5 the cube acceleration of coupled lanes, row 6 the lane's
-// contact code (count | coupled << 8 | dropped << 16).
+// With the finger-pad contact flags (PADS) wave 3 -- idle otherwise, and with an empty register file: it holds no env state --
+// is the CONTACT WAVE of the workgroup.  Per substep, concurrently with RNEA (wave 1) / CRBA + factorisation (wave 0) /
+// cube_prepare (wave 2): world-frame kinematics and the pad narrowphase, records into LDS (cbuf, [record][field][lane]) and, if
+// any of its lanes has a contact, its own copy of the CRBA mass matrix (the primal solve needs M itself, not its factor).  After
+// the mid-substep barrier it solves the lanes that have contacts in the primal (so100_contact.hpp) while wave 0 runs the block
+// PGS for all lanes as before; a third barrier later wave 0 takes the contact wave's acceleration for the lanes that had
+// contacts, and wave 2 the cube's for lanes whose pad touches the cube (arm + cube solved together), and both integrate.
+// (The first version ran the Newton on wave 0 beside the env state: 409 scratch accesses in the kernel, 78 % of the wave's
+// cycles waiting on them, 600 us per step in sustained contact.)
+// LDS: xq [24][64] = sin q, cos q, v, q; xk [12][64] = ctrl, arm warm start (written once per env step); xa [14][64] = arm
+// acceleration (0-5) and cube acceleration (6-11) of the contact wave's solve, contact code (12: count | coupled << 8 |
+// dropped << 16), solver residual (13).
+struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; };
+
 template <bool PADS, class Hook>
 __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, const float ctrl[6], float cstale[3],
-                                                 Arm<float>& A, float (&xq)[18][64], float (&xc)[24][64], float (&xb)[6][64],
-                                                 float* cbuf, float (*xa)[64], Prof& prof_, Hook after_first_barrier) {
+                                                 Arm<float>& A, const PhaseLds& L, Prof& prof_, Hook after_first_barrier) {
+    float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
     // for the substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
@@ -78,7 +85,14 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     const bool padcube = PADS && (p.flags & F_PADS_CUBE) != 0u && cube_live;
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
-    if (wave == 0) { e.res = 0.0f; e.cstat = 0; }
+    float aw3[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };       // contact wave: arm acceleration of its last solve (Newton warm start)
+    if (wave == 0) {
+        e.res = 0.0f; e.cstat = 0;
+        if (pads) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) { xk[i][lane] = ctrl[i]; xk[6 + i][lane] = e.aw[i]; }
+        }
+    }
     if (cube_live) {
         if (wave == 0) {
 #pragma unroll
@@ -99,8 +113,13 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             for (int i = 0; i < 6; i++) { cb.vel[i] = xc[7 + i][lane]; cb.warm[i] = xc[13 + i][lane]; }
             applied[2] = xc[19][lane];
         }
-    } else if (wave == 0) {
-        cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2];      // kinematic cube
+    } else {
+        if (wave == 0) { cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2]; }      // kinematic cube
+        if (pads) __syncthreads();                         // xk visible to the contact wave
+    }
+    if (pads && wave == 3) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) aw3[i] = xk[6 + i][lane];
     }
 #pragma unroll 1
     for (int sub = 0; sub < p.frame_skip; sub++) {
@@ -109,6 +128,10 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             if (sub == 0) arm_trig<float>(e.q, A); else arm_trig_update<float>(e.q, dq, A);
 #pragma unroll
             for (int i = 0; i < 6; i++) { xq[i][lane] = A.s[i]; xq[6 + i][lane] = A.c[i]; xq[12 + i][lane] = e.v[i]; }
+            if (pads) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) xq[18 + i][lane] = e.q[i];
+            }
             SO100_PROF(2);                                 // trig (wave 0)
         }
         if (padcube && wave == 2 && sub > 0) {             // the cube's pose for this substep's narrowphase / coupled solve
@@ -122,6 +145,10 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         __syncthreads();
         SO100_PROF(3);                                     // barrier 1 wait
         after_first_barrier(sub);
+        // ---- first half of the substep: everything that does not need the other waves' results
+        WorldFK<float> W3; Arm<float> A3; ContactsLds<float> cs3{ L.cbuf, lane };     // contact wave only
+        float Rc3[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f }, cpos3[3] = { 0.0f, 0.0f, 0.0f };
+        bool coupled3 = false, any3 = false;
         if (wave == 1) {
             float v1[6];
 #pragma unroll
@@ -139,79 +166,98 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             cube_prepare<float>(cb, applied, p.flags, cprep);           // contact detection + row setup ...
             SO100_PROF(4);                                 // cube_prepare (wave 2)
         } else if (wave == 3 && pads) {
-            // world FK of the joint frames + pad narrowphase -> contact records in LDS
-            float s3[6], c3[6], v3[6];
+            float v3[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { s3[i] = xq[i][lane]; c3[i] = xq[6 + i][lane]; v3[i] = xq[12 + i][lane]; }
-            WorldFK<float> W;
-            world_fk<float>(s3, c3, W);
-            Cube<float> c3b; float Rc[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
+            for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][lane]; A3.c[i] = xq[6 + i][lane]; v3[i] = xq[12 + i][lane]; }
+            world_fk<float>(A3.s, A3.c, W3);
+            Cube<float> c3b;
+#pragma unroll
+            for (int i = 0; i < 3; i++) c3b.pos[i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3b.vel[i] = 0.0f;
             if (padcube) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) c3b.pos[i] = xc[i][lane];
+                for (int i = 0; i < 3; i++) { c3b.pos[i] = xc[i][lane]; cpos3[i] = c3b.pos[i]; }
                 float qn[4] = { xc[3][lane], xc[4][lane], xc[5][lane], xc[6][lane] };
 #pragma unroll
                 for (int i = 0; i < 6; i++) c3b.vel[i] = xc[7 + i][lane];
-                quat_normalize(qn); quat_to_mat(qn, Rc);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 3; i++) c3b.pos[i] = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 6; i++) c3b.vel[i] = 0.0f;
+                quat_normalize(qn); quat_to_mat(qn, Rc3);
             }
-            ContactsLds<float> cs{ cbuf, lane };
-            const bool coupled = detect_pad_contacts<float>(W, v3, c3b, Rc, p.flags, padcube, cs);
-            xa[6][lane] = __int_as_float(cs.n | (coupled ? 256 : 0) | ((cs.dropped > 0xFFFF ? 0xFFFF : cs.dropped) << 16));
-            SO100_PROF(4);
+            coupled3 = detect_pad_contacts<float>(W3, v3, c3b, Rc3, p.flags, padcube, cs3);
+            xa[12][lane] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
+            any3 = __any(cs3.n > 0);
+            if (any3) arm_mass<float>(A3);                 // the mass matrix itself (wave 0 keeps only its factor)
+            SO100_PROF(4);                                 // FK + narrowphase (+ CRBA) (wave 3)
         }
         __syncthreads();
         SO100_PROF(5);                                     // barrier 2 wait
-        float cal[3], caa[3];
+        // ---- second half: solves
+        float cal[3], caa[3], acc0[6]; ArmRows<float> r0;
         if (wave == 2 && cube_live) { cube_solve<float>(cb, p.flags, p.contact_iters, cprep, cal, caa); SO100_PROF(6); }   // Newton behind the arm's solve
         if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 6; i++) A.bias[i] = xb[i][lane];
-            const int code = pads ? __float_as_int(xa[6][lane]) : 0;
-            const int nc = code & 255;
-            if (nc > 0) {
-                const bool coupled = (code & 256) != 0;
-                WorldFK<float> W;
-                world_fk<float>(A.s, A.c, W);
-                ContactsLds<float> cs{ cbuf, lane }; cs.n = nc;
-                Cube<float> ct; float Rc[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f };
-                float ap[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
-#pragma unroll
-                for (int i = 0; i < 3; i++) ct.pos[i] = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 6; i++) ct.warm[i] = 0.0f;
-                if (coupled) {
-#pragma unroll
-                    for (int i = 0; i < 3; i++) ct.pos[i] = xc[i][lane];
-                    float qn[4] = { xc[3][lane], xc[4][lane], xc[5][lane], xc[6][lane] };
-#pragma unroll
-                    for (int i = 0; i < 6; i++) ct.warm[i] = xc[13 + i][lane];
-                    quat_normalize(qn); quat_to_mat(qn, Rc);
-                }
-                float xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-                contact_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, p.flags, p.contact_iters, A, W, cs, coupled, ct, Rc, ap, dq, &e.res, xcube);
-                if (coupled) {
-#pragma unroll
-                    for (int i = 0; i < 6; i++) xa[i][lane] = xcube[i];
-                }
+            float tau[6];
+            arm_tau<float>(e.q, e.v, ctrl, A, tau);
+            if ((p.flags & (F_FRICTIONLOSS | F_LIMITS)) != 0u) {
+                arm_rows<float>(e.q, e.v, tau, e.ff, e.fl, p.flags, A, r0);
+                float res;
+                arm_pgs<float>(e.ff, e.fl, p.solver_iters, A, r0, acc0, res);
+                e.res = tmax(e.res, res);
             } else {
-                arm_solve_integrate<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, dq, &e.res, pads ? e.aw : nullptr);
+                if (pads) arm_row_consts<float>(e.q, e.v, p.flags, r0);
+#pragma unroll
+                for (int i = 0; i < 6; i++) acc0[i] = tau[i];
+                ldl6_solve<float>(A.M, A.Dinv, acc0);
             }
+            SO100_PROF(6);                                 // solve (wave 0)
+        }
+        if (wave == 3 && pads && any3) {
+            if (cs3.n > 0) {
+                float q3[6], v3[6], c3[6], tau3[6], x3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][lane]; v3[i] = xq[12 + i][lane]; c3[i] = xk[i][lane]; A3.bias[i] = xb[i][lane]; x3[i] = aw3[i]; cwarm[i] = 0.0f; }
+                arm_tau<float>(q3, v3, c3, A3, tau3);
+                ArmRows<float> r3;
+                arm_row_consts<float>(q3, v3, p.flags, r3);
+                if (coupled3) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][lane];
+                    ap3[2] = xc[19][lane];
+                }
+                const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube);
+#pragma unroll
+                for (int i = 0; i < 6; i++) { xa[i][lane] = x3[i]; xa[6 + i][lane] = xcube[i]; aw3[i] = x3[i]; }
+                xa[13][lane] = res;
+            }
+            SO100_PROF(6);                                 // contact Newton (wave 3)
+        }
+        if (pads) __syncthreads();                         // the contact wave's accelerations are in xa
+        if (wave == 0) {
             if (pads) {
+                const int code = __float_as_int(xa[12][lane]);
+                const int nc = code & 255;
+                if (nc > 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) acc0[i] = xa[i][lane];
+                    arm_row_forces<float>(r0, acc0, e.ff, e.fl);          // the block PGS's warm-start memory for when the contact is gone
+                    e.res = tmax(e.res, xa[13][lane]);
+                }
+#pragma unroll
+                for (int i = 0; i < 6; i++) e.aw[i] = acc0[i];
                 const int n0 = e.cstat & 255, dr = (e.cstat >> 8) + (code >> 16);
                 e.cstat = (nc > n0 ? nc : n0) | ((dr > 0xFFFF ? 0xFFFF : dr) << 8);
             }
-            SO100_PROF(6);                                 // solve + integrate (wave 0)
+            arm_integrate<float>(e.q, e.v, e.qc, acc0, dq);
         }
-        if (padcube) __syncthreads();                      // coupled lanes: the cube's acceleration comes from wave 0's 12-dof solve
-        if (wave == 2 && cube_live) {
-            if (padcube && (__float_as_int(xa[6][lane]) & 256) != 0) {
+        if (wave == 3 && pads && !(cs3.n > 0)) {           // keep the warm start current for lanes that were solved by the block PGS
 #pragma unroll
-                for (int i = 0; i < 3; i++) { cal[i] = xa[i][lane]; caa[i] = xa[3 + i][lane]; cb.warm[i] = cal[i] - cprep.a0[i]; cb.warm[3 + i] = caa[i]; }
+            for (int i = 0; i < 6; i++) aw3[i] = 0.0f;
+        }
+        if (wave == 2 && cube_live) {
+            if (padcube && (__float_as_int(xa[12][lane]) & 256) != 0) {      // arm and cube were solved together on the contact wave
+#pragma unroll
+                for (int i = 0; i < 3; i++) { cal[i] = xa[6 + i][lane]; caa[i] = xa[9 + i][lane]; cb.warm[i] = cal[i] - cprep.a0[i]; cb.warm[3 + i] = caa[i]; }
             }
             cube_integrate<float>(cb, cal, caa);
         }
@@ -398,10 +444,11 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     float (*h1t)[64][LD] = hbuf[0]; float (*h2t)[64][LD] = hbuf[1];
     static_assert(sizeof(hbuf) >= sizeof(float)*MAXC*CF*64, "contact records must fit under the activation images");
     constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
-    __shared__ float xa[PADS ? 8 : 1][64];                        // pad contacts: cube acceleration of coupled lanes + per-lane contact code
+    __shared__ float xa[PADS ? 14 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual
+    __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
     __shared__ float xmean[6][64];                                // action means, two per wave (waves 0, 1, 3 -> wave 0)
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
-    __shared__ float xq[18][64];                                  // physics split: sin q, cos q, v of env = lane (wave 0 -> wave 1)
+    __shared__ float xq[PADS ? 24 : 18][64];                      // physics split: sin q, cos q, v (+ q) of env = lane (wave 0 -> waves 1, 3)
     __shared__ float xc[24][64];                                  //                cube state hand-over (wave 0 <-> wave 2)
     __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
     if (FL >= 0) p.flags = (unsigned)FL;
@@ -544,7 +591,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
-            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, xq, xc, xb, &hbuf[0][0][0][0], xa, prof_, [&](int sub) {
+            const PhaseLds lds{ xq, xc, xb, &hbuf[0][0][0][0], xa, xk };
+            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
                     policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
