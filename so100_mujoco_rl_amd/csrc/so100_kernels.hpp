@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     __shared__ float cbuf[PADS ? MAXC*CF*64 : 1];                 // pad contact records [record][field][lane]
     __shared__ float xa[PADS ? 14 : 1][64];
     __shared__ float xk[PADS ? 12 : 1][64];
+    __shared__ float xm[PADS ? 21 : 1][64];
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
         env_step_pre<KIND>(e, a, u, p, ctx);
     }
     Arm<float> A; Prof prof_;
-    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk };
+    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm };
     physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [](int) {});
     if (wave != 0 || !live) return;
     e.nsub += p.frame_skip;

@@ -71,12 +71,13 @@ struct Prof {
 // LDS: xq [24][64] = sin q, cos q, v, q; xk [12][64] = ctrl, arm warm start (written once per env step); xa [14][64] = arm
 // acceleration (0-5) and cube acceleration (6-11) of the contact wave's solve, contact code (12: count | coupled << 8 |
 // dropped << 16), solver residual (13).
-struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; };
+// xm [21][64] = the arm's mass matrix (packed lower, unfactored), published by wave 0 before it factorises it in place.
+struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; };
 
 template <bool PADS, class Hook>
 __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, const float ctrl[6], float cstale[3],
                                                  Arm<float>& A, const PhaseLds& L, Prof& prof_, Hook after_first_barrier) {
-    float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk;
+    float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk; float (*xm)[64] = L.xm;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
     // for the substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
@@ -159,6 +160,10 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             SO100_PROF(4);                                 // RNEA (wave 1)
         } else if (wave == 0) {
             arm_mass<float>(A);
+            if (pads) {                                    // the contact wave's primal solve needs M itself
+#pragma unroll
+                for (int i = 0; i < 21; i++) xm[i][lane] = A.M[i];
+            }
             arm_factor<float>(p.flags, A);          // everything that needs only M happens before the barrier
             SO100_PROF(4);                                 // CRBA + factor (wave 0)
         } else if (wave == 2 && cube_live) {
@@ -186,8 +191,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             coupled3 = detect_pad_contacts<float>(W3, v3, c3b, Rc3, p.flags, padcube, cs3);
             xa[12][lane] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
             any3 = __any(cs3.n > 0);
-            if (any3) arm_mass<float>(A3);                 // the mass matrix itself (wave 0 keeps only its factor)
-            SO100_PROF(4);                                 // FK + narrowphase (+ CRBA) (wave 3)
+            SO100_PROF(4);                                 // FK + narrowphase (wave 3)
         }
         __syncthreads();
         SO100_PROF(5);                                     // barrier 2 wait
@@ -215,6 +219,8 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         if (wave == 3 && pads && any3) {
             if (cs3.n > 0) {
                 float q3[6], v3[6], c3[6], tau3[6], x3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                for (int i = 0; i < 21; i++) A3.M[i] = xm[i][lane];
 #pragma unroll
                 for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][lane]; v3[i] = xq[12 + i][lane]; c3[i] = xk[i][lane]; A3.bias[i] = xb[i][lane]; x3[i] = aw3[i]; cwarm[i] = 0.0f; }
                 arm_tau<float>(q3, v3, c3, A3, tau3);
@@ -438,15 +444,18 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     constexpr int LD = 65;                                        // LDS row stride of the [env][unit] activation images
     __shared__ __attribute__((aligned(16))) float hd[6*64 + 64 + 16];   // mu_w | v_w | mu_b(6) log_std(6) v_b(1)
     __shared__ float oxt[64][ODP + 1];                            // observation [env][k]
-    // both hidden-activation images in one array: they are dead during the physics phase, when the pad-contact records
-    // ([MAXC][CF][64] floats = 61 440 B) live in the same bytes
-    __shared__ float hbuf[2][2][64][LD];
-    float (*h1t)[64][LD] = hbuf[0]; float (*h2t)[64][LD] = hbuf[1];
-    static_assert(sizeof(hbuf) >= sizeof(float)*MAXC*CF*64, "contact records must fit under the activation images");
+    // The hidden-activation images and the action means in ONE array: they are dead during the physics phase, when the bytes
+    // carry the pad-contact records ([MAXC][CF][64] floats = 61 440 B) and the mass matrix for the contact wave ([21][64]).
+    constexpr int HB = 2*2*64*LD;                                 // floats of the two activation images
+    __shared__ float pool[HB + 6*64];
+    float (*h1t)[64][LD] = reinterpret_cast<float (*)[64][LD]>(pool);
+    float (*h2t)[64][LD] = reinterpret_cast<float (*)[64][LD]>(pool + 2*64*LD);
+    float (*xmean)[64] = reinterpret_cast<float (*)[64]>(pool + HB);   // action means, two per wave (waves 0, 1, 3 -> wave 0)
+    float (*xm)[64] = reinterpret_cast<float (*)[64]>(pool + MAXC*CF*64);
+    static_assert(HB + 6*64 >= MAXC*CF*64 + 21*64, "contact records + mass matrix must fit under the policy phase's images");
     constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
     __shared__ float xa[PADS ? 14 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual
     __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
-    __shared__ float xmean[6][64];                                // action means, two per wave (waves 0, 1, 3 -> wave 0)
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
     __shared__ float xq[PADS ? 24 : 18][64];                      // physics split: sin q, cos q, v (+ q) of env = lane (wave 0 -> waves 1, 3)
     __shared__ float xc[24][64];                                  //                cube state hand-over (wave 0 <-> wave 2)
@@ -591,7 +600,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
-            const PhaseLds lds{ xq, xc, xb, &hbuf[0][0][0][0], xa, xk };
+                        const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm };
             physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
