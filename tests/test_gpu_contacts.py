@@ -231,4 +231,8 @@ def test_contact_kernels_agree_with_each_other(flags):
         same = (o[2] & 255) == (ref[2] & 255)
         assert same.float().mean() > 0.9, name
         dq = (o[0] - ref[0]).abs().amax(0); dv = (o[1] - ref[1]).abs().amax(0)
-        assert dq[same].max() < 2e-5 and dv[same].max() < 2e-2, (name, float(dq[same].max()), float(dv[same].max()))
+        # the kernels differ in their Newton warm starts (the contact wave of the multi-wave kernels starts a lane's first contact
+        # substep cold, the one-wave kernel carries the previous acceleration) and tiny steps are taken unverified, so they agree
+        # to the solver tolerance per substep, and to the make / break bound of the module docstring over three env steps
+        assert dq[same].max() < 2e-4 and dv[same].max() < 1e-1, (name, float(dq[same].max()), float(dv[same].max()))
+        assert dq[same].median() < 2e-6 and dv[same].median() < 2e-4, (name, float(dq[same].median()), float(dv[same].median()))
