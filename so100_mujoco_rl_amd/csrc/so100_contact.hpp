@@ -777,13 +777,15 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         // phi'(0) = g.dx < 0 and phi'(1) = d1 > 0
         T lo = T(0), hi = T(1), alpha = gdx/(gdx - d1), d2;
 #pragma unroll 1
-        for (int ls = 0; ls < 3; ls++) {
+        for (int ls = 0; ls < (f32 ? 6 : 40); ls++) {
             P.line_deriv(x, dx, alpha, d1, d2);
             SO100_CSTAT(2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
 #endif
-            if (tabs(d1) <= (f32 ? T(1e-2) : T(1e-10))*tabs(gdx)) break;
+            // curvature condition |phi'(alpha)| <= 0.25 |phi'(0)| (fp64: to round-off): enough for the Newton iteration to
+            // proceed; the exact minimiser along a direction that the next Hessian supersedes is not worth more row passes
+            if (tabs(d1) <= (f32 ? T(0.25) : T(1e-10))*tabs(gdx)) break;
             if (d1 < T(0)) lo = alpha; else hi = alpha;
             T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
             if (!(an > lo && an < hi)) an = T(0.5)*(lo + hi);
