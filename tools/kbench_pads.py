@@ -10,9 +10,9 @@ from so100_mujoco_rl_amd.collector import RolloutCollector
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 T = 64
-for flags, name in ((F_NOPADS, "nopads"), (F_REFERENCE, "reference"), (F_CONTACT5, "contact5")):
+for flags, name in ((F_NOPADS, "nopads"), (F_REFERENCE, "reference"), (F_CONTACT5, "contact5"))[int(os.environ.get("SKIP", "0")):]:
     for mode in ("raised", "random"):
-        sim = So100Sim(1, n, flags=flags, seed=1)
+        sim = So100Sim(1, n, flags=flags, seed=1, contact_iters=int(os.environ.get('CIT', '6')))
         sd = RolloutCollector.random_policy_state(15, sim.device, seed=0)
         if mode == "raised":
             sd["action_net.weight"].zero_(); sd["action_net.bias"].zero_(); sd["log_std"].fill_(-30.0)
