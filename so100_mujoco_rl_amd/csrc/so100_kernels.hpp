@@ -201,7 +201,15 @@ template <int KIND> struct KindOps {
     static hipError_t reset(const SimParams& prm, float* state, const float* start_tab, const uint8_t* mask, const float* inject, float* obs, hipStream_t st);
     static hipError_t init(int n, float* state);
     static hipError_t rollout(const SimParams& prm, float* state, const float* start_tab, const RolloutPtrs& io, const PolicyWeights& pw, const RolloutArgs& ra, hipStream_t st);
+#ifdef SO100_ROLLOUT_PROF
+    static int prof_read(long long* out48);       // the cycle counters live in the kind's own code object
+#endif
 };
+#ifdef SO100_ROLLOUT_PROF
+template <int KIND> int KindOps<KIND>::prof_read(long long* out48) {
+    return hipMemcpyFromSymbol(out48, HIP_SYMBOL(so100_prof), sizeof(long long)*48) == hipSuccess ? 0 : -1;
+}
+#endif
 
 template <int KIND> hipError_t KindOps<KIND>::step(const SimParams& prm, const StepPtrs& io, hipStream_t st) {
     const bool mw = prm.n <= MW_MAX_ENVS;

@@ -31,11 +31,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Optional cycle accounting of the persistent kernel's phases (tools/rollout_prof.py builds a side library with
 // -DSO100_ROLLOUT_PROF; the product library compiles these to nothing).  Slots: see tools/rollout_prof.py.
 #ifdef SO100_ROLLOUT_PROF
-__device__ long long so100_prof[32];
+__device__ long long so100_prof[48];
 struct Prof {
-    long long t[8] = {}, c = __builtin_readcyclecounter();
+    long long t[10] = {}, c = __builtin_readcyclecounter();
     __device__ __forceinline__ void mark(int slot) { const long long n = __builtin_readcyclecounter(); t[slot] += n - c; c = n; }
-    __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 8; i++) so100_prof[base + i] = t[i]; }
+    __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 10; i++) so100_prof[base + i] = t[i]; }
 };
 #else
 struct Prof {
@@ -239,6 +239,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             SO100_PROF(6);                                 // contact Newton (wave 3)
         }
         if (pads) __syncthreads();                         // the contact wave's accelerations are in xa
+        SO100_PROF(8);                                     // barrier 3 wait
         if (wave == 0) {
             if (pads) {
                 const int code = __float_as_int(xa[12][lane]);
@@ -267,6 +268,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             }
             cube_integrate<float>(cb, cal, caa);
         }
+        SO100_PROF(9);                                     // integrate
     }
     if (cube_live) {
         if (wave == 2) {
@@ -638,7 +640,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         }
         __syncthreads();
     }
-    if (wave < 3) SO100_PROF_FLUSH(8*wave);
+    SO100_PROF_FLUSH(10*wave);
     if (wave == 0 && live) {
         store_env_state<KIND, FL>(state, p.n, env, e);
         if (ra.T > 0) {

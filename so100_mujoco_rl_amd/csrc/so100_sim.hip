@@ -64,7 +64,7 @@ int so100_state_field_index(const char* name) {
 const char* so100_state_field_name(int32_t field) { return (field >= 0 && field < SF_COUNT) ? kFieldNames[field] : nullptr; }
 const char* so100_last_error(void) { return g_err; }
 #ifdef SO100_ROLLOUT_PROF
-int so100_prof_read(long long* out32) { return hipMemcpyFromSymbol(out32, HIP_SYMBOL(so100::so100_prof), sizeof(long long)*32) == hipSuccess ? 0 : -1; }
+int so100_prof_read(int kind, long long* out48) { return DISPATCH_KIND(kind, prof_read)(out48); }
 #endif
 
 int so100_create(const so100_config* cfg, so100_sim** out) {

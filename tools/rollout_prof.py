@@ -1,43 +1,54 @@
-"""Cycle accounting of the persistent rollout kernel's phases (wave 0 / 1 / 2 of workgroup 0).
+"""Cycle accounting of the persistent rollout kernel's phases (waves 0-3 of workgroup 0).
 Build the instrumented side library HERE (no GPU needed), then run on the GPU box:
     python tools/rollout_prof.py build
-    gpurun -- python tools/rollout_prof.py [free|arm|ref]
+    gpurun -- python tools/rollout_prof.py [free|arm|nopads|ref|c5] [random|resting]
 The product library is untouched (the instrumentation is compiled out without -DSO100_ROLLOUT_PROF)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SIDE = os.path.join(ROOT, "so100_mujoco_rl_amd", "libso100sim_prof.so")
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     import torch
+    from concurrent.futures import ThreadPoolExecutor
     tl = os.path.join(os.path.dirname(torch.__file__), "lib")
     csrc = os.path.join(ROOT, "so100_mujoco_rl_amd", "csrc")
-    obj = os.path.join(ROOT, "gpurun_out", "so100_sim_prof.o"); os.makedirs(os.path.dirname(obj), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-ffp-contract=fast",
-                           "-fno-slp-vectorize", "-Wno-unused-function", "-DSO100_ROLLOUT_PROF", "-c", "-o", obj, os.path.join(csrc, "so100_sim.hip")])
-    subprocess.check_call(["g++", "-shared", "-o", SIDE, obj, "-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib", "-lstdc++", "-lm"])
+    odir = os.path.join(ROOT, "gpurun_out", "prof_obj"); os.makedirs(odir, exist_ok=True)
+    base = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-gpu-rdc", "-ffp-contract=fast",
+            "-fno-slp-vectorize", "-Wno-unused-function", "-DSO100_ROLLOUT_PROF", "-c"]
+    jobs = [(base + ["-o", os.path.join(odir, "sim.o"), os.path.join(csrc, "so100_sim.hip")])]
+    jobs += [(base + [f"-DSO100_KIND={k}", "-o", os.path.join(odir, f"kind{k}.o"), os.path.join(csrc, "so100_kind.hip")]) for k in range(1, 7)]
+    with ThreadPoolExecutor(7) as ex:
+        list(ex.map(subprocess.check_call, jobs))
+    objs = [os.path.join(odir, "sim.o")] + [os.path.join(odir, f"kind{k}.o") for k in range(1, 7)]
+    subprocess.check_call(["g++", "-shared", "-o", SIDE] + objs + ["-L" + tl, "-lamdhip64", "-Wl,-rpath," + tl, "-Wl,-rpath,/opt/rocm/lib", "-lstdc++", "-lm"])
     print("built", SIDE); sys.exit(0)
 os.environ["SO100_LIB"] = SIDE
 sys.path.insert(0, ROOT)
 import torch
 from so100_mujoco_rl_amd import lib
-from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE, F_FRICTIONLOSS, F_LIMITS
+from so100_mujoco_rl_amd.lib import So100Sim, F_CUBE_PINNED, F_REFERENCE, F_NOPADS, F_CONTACT5, F_FRICTIONLOSS, F_LIMITS
 from so100_mujoco_rl_amd.collector import RolloutCollector, SB3_STATE_DICT_KEYS, POLICY_TENSORS
 which = sys.argv[1] if len(sys.argv) > 1 else "free"
-flags = {"free": F_CUBE_PINNED, "arm": F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED, "ref": F_REFERENCE}[which]
+mode = sys.argv[2] if len(sys.argv) > 2 else "random"
+flags = {"free": F_CUBE_PINNED, "arm": F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED, "nopads": F_NOPADS, "ref": F_REFERENCE, "c5": F_CONTACT5}[which]
 n, T = 4096, 64
 sim = So100Sim(1, n, flags=flags, seed=1); sim.reset()
 sd = RolloutCollector.random_policy_state(sim.obs_dim, sim.device, seed=0)
+if mode == "resting":                       # zero action: Env01's ctrl = measured angle lets every arm sag onto the floor and rest there
+    sd["action_net.weight"].zero_(); sd["action_net.bias"].zero_(); sd["log_std"].fill_(-30.0)
 sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
 buf = torch.empty(T, n, sim.obs_dim + 10, device="cuda")
-for i in range(3):
+for i in range(4):
     sim.rollout(buf, i * T)
 torch.cuda.synchronize()
-out = (C.c_longlong * 32)()
-assert sim.L.so100_prof_read(out) == 0
-names = ["policy layers (MFMA+tanh, 2 barriers)", "head+noise+row+env_step_pre", "trig + publish", "barrier-1 wait", "CRBA+factor (w0) / RNEA (w1)",
-         "barrier-2 wait", "solve+integrate (w0)", "step tail: poses, obs, reset, end barrier"]
-for w in range(3):
-    v = [out[8 * w + i] for i in range(8)]; tot = sum(v)
+out = (C.c_longlong * 48)()
+assert sim.L.so100_prof_read(1, out) == 0
+names = ["policy layers (MFMA+tanh, 2 barriers)", "head+noise+row+env_step_pre", "trig + publish", "barrier-1 wait",
+         "phase 1: CRBA+factor (w0) / RNEA (w1) / cube_prepare (w2) / FK+narrowphase (w3)", "barrier-2 wait",
+         "phase 2: PGS (w0) / cube Newton (w2) / contact Newton (w3)", "step tail: poses, obs, reset, end barrier", "barrier-3 wait", "integrate"]
+print(f"# tools/rollout_prof.py {which} {mode}   (Env01 x {n}, epw {16 if flags & 4 else 64})")
+for w in range(4):
+    v = [out[10 * w + i] for i in range(10)]; tot = sum(v)
     print(f"wave {w}: total {tot / T:9.0f} ticks/step")
     for nm, x in zip(names, v):
-        per = "  (%.0f / substep)" % (x / T / 16) if nm.split()[0] in ("trig", "barrier-1", "CRBA+factor", "barrier-2", "solve+integrate") else ""
-        print(f"    {nm:42s} {x / T:9.0f} ticks/step  {100.0 * x / max(tot, 1):5.1f} %{per}")
+        per = "  (%.0f / substep)" % (x / T / 16) if nm.split()[0] in ("trig", "barrier-1", "phase", "barrier-2", "barrier-3", "integrate") else ""
+        print(f"    {nm:84s} {x / T:9.0f} ticks/step  {100.0 * x / max(tot, 1):5.1f} %{per}")
