@@ -126,7 +126,11 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     }
     Arm<float> A; Prof prof_;
     const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm };
-    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [](int) {});
+    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [](int) {}, [&]() {
+        ctx = StepCtx{};
+#pragma unroll
+        for (int k = 0; k < 8; k++) u[k] = 0.0f;
+    });
     if (wave != 0 || !live) return;
     e.nsub += p.frame_skip;
     TaskPoses<float> P;

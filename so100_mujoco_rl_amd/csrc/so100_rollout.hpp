@@ -74,9 +74,14 @@ struct Prof {
 // xm [21][64] = the arm's mass matrix (packed lower, unfactored), published by wave 0 before it factorises it in place.
 struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; };
 
-template <bool PADS, class Hook>
-__device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, const float ctrl[6], float cstale[3],
-                                                 Arm<float>& A, const PhaseLds& L, Prof& prof_, Hook after_first_barrier) {
+// Register pressure.  The kernel is ONE control-flow graph: whatever another wave will read later (wave 0's env state `e`, its
+// mass-matrix factor A, wave 2's cube block) is live across the contact wave's Newton as far as the register allocator can
+// tell, although those registers hold nothing on wave 3.  After its solve the contact wave therefore overwrites all of it
+// with constants (`forget`, the caller's `forget_caller_state` for what lives outside this function): every path from the
+// Newton to a use passes that definition, so the old values are dead during the solve and their registers are free.
+template <bool PADS, class Hook, class Forget>
+__device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, float ctrl[6], float cstale[3],
+                                                 Arm<float>& A, const PhaseLds& L, Prof& prof_, Hook after_first_barrier, Forget forget_caller_state) {
     float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk; float (*xm)[64] = L.xm;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
@@ -236,6 +241,12 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                 for (int i = 0; i < 6; i++) { xa[i][lane] = x3[i]; xa[6 + i][lane] = xcube[i]; aw3[i] = x3[i]; }
                 xa[13][lane] = res;
             }
+            // (see "Register pressure" above)
+            e = EnvState{}; A = Arm<float>{}; cb = Cube<float>{}; cprep = CubePrep<float>{};
+#pragma unroll
+            for (int i = 0; i < 6; i++) { dq[i] = 0.0f; ctrl[i] = 0.0f; }
+            applied[0] = applied[1] = applied[2] = 0.0f; cstale[0] = cstale[1] = cstale[2] = 0.0f;
+            forget_caller_state();
             SO100_PROF(6);                                 // contact Newton (wave 3)
         }
         if (pads) __syncthreads();                         // the contact wave's accelerations are in xa
@@ -610,6 +621,12 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
 #pragma unroll
                     for (int a = 0; a < 6; a++) xn[a][lane] = eps[a];
                 }
+            }, [&]() {                                             // contact wave: wave 0's step-scope state is not ours to keep alive
+                ctx = StepCtx{}; last = StepResult{};
+#pragma unroll
+                for (int k = 0; k < 8; k++) ustep[k] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < OD; k++) last_obs[k] = 0.0f;
             });
             if (wave == 0) {
                 e.nsub += p.frame_skip;
