@@ -493,7 +493,9 @@ def test_persistent_rollout_equals_stepwise(kind, flags):
     (a1, a2, aq, av, at, al), (s1, s2, sq, sv, st_, sl) = outs
     for a, s in ((a1, s1), (a2, s2)):
         for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
-            assert torch.allclose(a[k], s[k], rtol=0, atol=1e-6), k
+            # separate compilations of the same code agree to an ulp or two of the angles (1e-6); the reward multiplies
+            # angle overshoots by 10 and end-effector heights by 20 (env_base_01.py:153-163, 207-211)
+            assert torch.allclose(a[k], s[k], rtol=0, atol=2e-5 if k == "rewards" else 1e-6), k
     assert torch.allclose(aq, sq, atol=1e-6) and torch.allclose(av, sv, atol=1e-5)
     assert a1["dones"].sum() > 0 and torch.equal(al, sl) and torch.allclose(at, st_, atol=1e-6)
 
