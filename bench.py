@@ -51,7 +51,8 @@ ROLLOUT_T = 64
 WORKLOADS = {
     "env01_free": (1, ("F_CUBE_PINNED",), "contact disabled, no constraint solver (BASELINE.json configs[1])"),
     "env01_arm": (1, ("F_FRICTIONLOSS", "F_LIMITS", "F_CUBE_PINNED"), "friction-loss + joint-limit rows, cube pinned"),
-    "env01_reference": (1, ("F_REFERENCE",), "reference physics: friction-loss + limits + cube/floor + pad/floor contact"),
+    "env01_nopads": (1, ("F_NOPADS",), "round-1 'reference': friction-loss + limits + cube/floor contact, no arm contact at all"),
+    "env01_reference": (1, ("F_REFERENCE",), "reference physics: friction-loss + limits + cube/floor + finger-pad/floor contact"),
     "env02_reference": (2, ("F_REFERENCE",), "reference physics (BASELINE.json configs[2] at this batch size)"),
     "env05_reference": (5, ("F_REFERENCE",), "reference physics (BASELINE.json configs[3] per-GPU shape)"),
     "env01_contact": (1, ("F_CONTACT5",), "reference physics + finger-pad/cube box-box contact, coupled arm+cube solve (BASELINE.json configs[4] per-GPU shape)"),
