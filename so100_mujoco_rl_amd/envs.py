@@ -25,6 +25,7 @@ class So100Env:
                                          max_episode_steps=K.MAX_EPISODE_STEPS[env_kind] if max_episode_steps is None else max_episode_steps)
         self._v = self._mk(seed)
         self.render_mode = render_mode
+        self._after_done = None          # observation of the episode the simulator has already started (see step)
 
     @property
     def sim(self):
@@ -32,15 +33,22 @@ class So100Env:
 
     def reset(self, *, seed=None, options=None):
         if seed is not None:                            # unlike the reference (global np.random) seeding works
-            self._v.close(); self._v = self._mk(int(seed))
+            self._v.close(); self._v = self._mk(int(seed)); self._after_done = None
+        if self._after_done is not None:                # the fused step already reset this env when the episode ended:
+            ob, self._after_done = self._after_done, None   # hand out THAT episode's first observation, do not reset twice
+            return ob, {}
         return self._v.reset()[0].copy(), {}
 
     def step(self, action):
-        # a single env never auto-resets in Gymnasium: run the step, report the terminal observation, and let the caller reset
+        """Gymnasium semantics on top of a simulator that auto-resets inside the fused step (SB3 VecEnv semantics):
+        on done the TERMINAL observation is returned and the next episode's first observation is kept for reset().
+        Stepping on without reset() -- what the reference's own viewer loop does for up to 200 steps after an episode
+        ends (main.py:118-124) -- simply continues in that next episode; no state is lost or reset twice either way."""
         self._v.step_async(np.asarray(action, np.float32).reshape(1, 6))
         obs, rew, done, infos = self._v.step_wait()
         d = bool(done[0]); tr = d and bool(infos[0].get("TimeLimit.truncated", False))
         ob = infos[0]["terminal_observation"].copy() if d else obs[0]
+        self._after_done = obs[0].copy() if d else None
         return ob, float(rew[0]), d and not tr, tr, {}
 
     def close(self):

@@ -550,8 +550,19 @@ def test_single_env_gym_view():
         ob, r, term, trunc, info = env.step(np.full(6, 0.3, np.float32))
         assert term is False and trunc is (t == 3)
     assert np.any(ob[6:] != 0)                                  # the terminal observation, not the all-zero-poses reset observation
+    rc0 = int(env.sim.get_field("rng_counter", dtype=torch.int32)[0])
     ob0, _ = env.reset()
     assert np.all(ob0[6:] == 0)
+    # the fused step had already reset the env when the episode ended: reset() hands out that episode's first observation and
+    # does NOT reset a second time (no extra RNG draw, elapsed_steps still 0) ...
+    assert int(env.sim.get_field("rng_counter", dtype=torch.int32)[0]) == rc0 and int(env.sim.get_field("elapsed_steps", dtype=torch.int32)[0]) == 0
+    np.testing.assert_array_equal(ob0[:6], env.sim.get_state()[0][:6, 0].cpu().numpy())
+    # ... and stepping on without reset() (the reference's viewer loop, main.py:118-124) continues in that next episode
+    for t in range(4):
+        ob, r, term, trunc, info = env.step(np.full(6, 0.3, np.float32))
+    assert trunc is True and int(env.sim.get_field("elapsed_steps", dtype=torch.int32)[0]) == 0
+    ob, r, term, trunc, info = env.step(np.zeros(6, np.float32))
+    assert trunc is False and int(env.sim.get_field("elapsed_steps", dtype=torch.int32)[0]) == 1
     t0 = time.perf_counter()
     for _ in range(300):
         env.step(np.zeros(6, np.float32))
