@@ -40,6 +40,10 @@ template <int KIND, int FL = -1> __device__ __forceinline__ void store_env_state
 
 #include "so100_rollout.hpp"
 
+#ifndef SO100_FREE_WAVES
+#define SO100_FREE_WAVES 2      // waves per SIMD asked of the contact-free throughput kernel (3 -> 168 VGPRs + 364 B of scratch: measured slower)
+#endif
+
 namespace so100 {
 
 constexpr int WG = 64;      // one wavefront per workgroup
@@ -59,7 +63,7 @@ struct StepPtrs {
 // batches need (1 M envs: 2 waves/SIMD 2.3 G env-steps/s, 1 wave/SIMD 1.5 G); the constrained variants and the
 // look-at envs (more task state) need > 256 and would spill.
 template <int KIND, int FL>
-__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_kind<KIND>()) ? 2 : 1)) so100_step_fused(SimParams p, StepPtrs io) {
+__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_kind<KIND>()) ? SO100_FREE_WAVES : 1)) so100_step_fused(SimParams p, StepPtrs io) {
     const int env = blockIdx.x*WG + threadIdx.x;
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
