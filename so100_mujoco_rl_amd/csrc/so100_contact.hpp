@@ -349,8 +349,24 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
     const T nz[3] = { T(0), T(0), T(1) };
     const T hc[3] = { T(so100g::CUBE_HALF), T(so100g::CUBE_HALF), T(so100g::CUBE_HALF) };
     bool coupled = false;
+    // every pad lies within PAD_REACH of its jaw's origin: a jaw higher than that above the floor / farther than that (+ the cube's
+    // circumradius) from the cube cannot touch; the per-pad tests below run only for lanes that fail this bound
+    constexpr double PAD_REACH = 0.115;
+    const T zmin = tmin(W.o[4][2], W.o[5][2]);
+    T dc2 = T(1e30);
+    if ((flags & F_PADS_CUBE) != 0u && cube_live) {
+#pragma unroll
+        for (int L = 4; L <= 5; L++) {
+            const T dx = W.o[L][0] - cube.pos[0], dy = W.o[L][1] - cube.pos[1], dz = W.o[L][2] - cube.pos[2];
+            dc2 = tmin(dc2, dx*dx + dy*dy + dz*dz);
+        }
+    }
+    const bool near_floor = (flags & F_PADS_FLOOR) != 0u && zmin < T(PAD_REACH);
+    const bool near_cube = dc2 < T((PAD_REACH + so100g::CUBE_HALF*1.7320508075688772)*(PAD_REACH + so100g::CUBE_HALF*1.7320508075688772));
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {                   // pass 0: pad/floor, pass 1: pad/cube
+        if (pass == 0 && !near_floor) continue;
+        if (pass == 1 && !near_cube) continue;
         if (pass == 0 && (flags & F_PADS_FLOOR) == 0u) continue;
         if (pass == 1 && ((flags & F_PADS_CUBE) == 0u || !cube_live)) continue;
 #pragma unroll 1
