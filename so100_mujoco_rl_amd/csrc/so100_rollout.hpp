@@ -127,21 +127,10 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
 #pragma unroll
         for (int i = 0; i < 6; i++) aw3[i] = xk[6 + i][lane];
     }
-    // Unless a pad can touch it (F_PADS_CUBE) the cube never meets the arm: wave 2 runs all of its substeps here, back to back,
-    // and only keeps the barrier count in the loop below (its 16 substeps are shorter than the arm's, so it is never waited for;
-    // in step with the arm its contact detection was the longest leg of the first half-substep).
-    const bool cube_in_step = cube_live && padcube;
-    if (cube_live && !padcube && wave == 2) {
-#pragma unroll 1
-        for (int sub = 0; sub < p.frame_skip; sub++) {
-            if (sub == p.frame_skip - 1) { xc[20][lane] = cb.pos[0]; xc[21][lane] = cb.pos[1]; xc[22][lane] = cb.pos[2]; }   // stale xpos (Q1)
-            cube_prepare<float>(cb, applied, p.flags, cprep);
-            float al[3], aa[3];
-            cube_solve<float>(cb, p.flags, p.contact_iters, cprep, al, aa);
-            cube_integrate<float>(cb, al, aa);
-        }
-        SO100_PROF(4);                                     // the cube's whole env step (wave 2)
-    }
+    // (Tried: letting wave 2 run the cube's 16 substeps back to back ahead of the arm when no pad can touch it.  A workgroup
+    // barrier needs every wave, so the others simply waited for it at the first one: 72 -> 101 us per step.  The cube stays in
+    // step with the arm: detection + row set-up in the first half-substep, Newton in the second.)
+    const bool cube_in_step = cube_live;
 #pragma unroll 1
     for (int sub = 0; sub < p.frame_skip; sub++) {
         if (wave == 0) {
@@ -288,7 +277,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             for (int i = 0; i < 6; i++) aw3[i] = 0.0f;
         }
         if (wave == 2 && cube_in_step) {
-            if ((__float_as_int(xa[12][lane]) & 256) != 0) {      // arm and cube were solved together on the contact wave
+            if (padcube && (__float_as_int(xa[12][lane]) & 256) != 0) {      // arm and cube were solved together on the contact wave
 #pragma unroll
                 for (int i = 0; i < 3; i++) { cal[i] = xa[6 + i][lane]; caa[i] = xa[9 + i][lane]; cb.warm[i] = cal[i] - cprep.a0[i]; cb.warm[3 + i] = caa[i]; }
             }
