@@ -796,7 +796,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         // phi'(0) = g.dx < 0 and phi'(1) = d1 > 0
         T lo = T(0), hi = T(1), alpha = gdx/(gdx - d1), d2;
 #pragma unroll 1
-        for (int ls = 0; ls < (f32 ? SO100_LS_PASSES : 40); ls++) {
+        for (int ls = 0; ls < (f32 ? (ND == 12 ? 6 : SO100_LS_PASSES) : 40); ls++) {      // (the coupled problem with its 8 g cube needs the better minimiser)
             P.line_deriv(x, dx, alpha, d1, d2);
             SO100_CSTAT(2);
 #if !defined(__HIPCC__)

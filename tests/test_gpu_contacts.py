@@ -235,4 +235,4 @@ def test_contact_kernels_agree_with_each_other(flags):
         # substep cold, the one-wave kernel carries the previous acceleration) and tiny steps are taken unverified, so they agree
         # to the solver tolerance per substep, and to the make / break bound of the module docstring over three env steps
         assert dq[same].max() < 2e-4 and dv[same].max() < 1e-1, (name, float(dq[same].max()), float(dv[same].max()))
-        assert dq[same].median() < 2e-6 and dv[same].median() < 2e-4, (name, float(dq[same].median()), float(dv[same].median()))
+        assert dq[same].median() < 5e-6 and dv[same].median() < 5e-4, (name, float(dq[same].median()), float(dv[same].median()))
