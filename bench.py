@@ -153,12 +153,23 @@ def launch_ranks(n_gpus, argv, worker=None, port=None):
            "--master-port", str(port), worker or os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
-    if proc.returncode == 0 and lines:
-        print(lines[-1], flush=True)
+    # rank 0's result line; the ranks share one stdout pipe, so another rank's output can land on the same line
+    result = None
+    dec = json.JSONDecoder()
+    for l in proc.stdout.splitlines():
+        i = l.find("{")
+        if i >= 0:
+            try:
+                obj, _ = dec.raw_decode(l[i:])
+                if isinstance(obj, dict):
+                    result = obj
+            except ValueError:
+                pass
+    if proc.returncode == 0 and result is not None:
+        print(json.dumps(result), flush=True)
     else:
         sys.stderr.write(proc.stdout)
-    return proc.returncode if proc.returncode != 0 else (0 if lines else 1)
+    return proc.returncode if proc.returncode != 0 else (0 if result is not None else 1)
 
 
 def large_batch_roofline(kind, flags, dev, n=1 << 20, reps=20):
