@@ -42,17 +42,27 @@ constexpr int CF = 12;                       // floats per contact record
 enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY, C_VZ };
 // C_P point (world, midway between the surfaces), C_N normal geom1 -> geom2 (the tangents follow from it: mju_makeFrame),
 // C_KD = K imp dist, C_RINV = 1/R of the 4 edge rows, C_V = B * relative point velocity (the velocity part of -aref),
-// C_KIND: 0 cube/floor, 1 / 2 pad/floor on link 4 / 5, 3 / 4 pad/cube with the pad on link 4 / 5
+// C_KIND: kind | id << 3 | mask0 << 11 (an integer held in a float) -- kind: 0 cube/floor, 1 / 2 pad/floor on link 4 / 5, 3 / 4 pad/cube
+// with the pad on link 4 / 5; id: which geometric feature made the contact (pad corner, manifold slot: stable from substep to substep);
+// mask0: the pyramid edges that carried force at the end of the previous substep's solve (the Newton's first guess of the active set).
+// The solver leaves (hash(id) << 4 | final mask), one byte, of every record in the store's "previous" list for the next substep's
+// detection (4-bit hash: distinct for the same corner of different pads; a collision only costs a worse first guess).
+SO100_HD int contact_id_hash(int id) { return (id ^ (id >> 4)) & 15; }
 
 template <typename T> struct ContactsPriv {                 // one env's records in a private array
     T a[MAXC*CF]; int n = 0, dropped = 0;
+    unsigned char pcode[MAXC]; int prev_n = 0;
     SO100_HD T get(int s, int f) const { return a[s*CF + f]; }
     SO100_HD void set(int s, int f, T v) { a[s*CF + f] = v; }
+    SO100_HD int getp(int k) const { return pcode[k]; }
+    SO100_HD void setp(int k, int v) { pcode[k] = (unsigned char)v; }
 };
 template <typename T> struct ContactsLds {                  // [record][field][lane] image shared by the waves of a workgroup
-    T* base; int lane; int n = 0, dropped = 0;
+    T* base; int lane; unsigned char* pbase; int n = 0, dropped = 0, prev_n = 0;       // pbase: [MAXC][64] bytes OUTSIDE any aliased region
     SO100_HD T get(int s, int f) const { return base[(s*CF + f)*64 + lane]; }
     SO100_HD void set(int s, int f, T v) { base[(s*CF + f)*64 + lane] = v; }
+    SO100_HD int getp(int k) const { return pbase[k*64 + lane]; }
+    SO100_HD void setp(int k, int v) { pbase[k*64 + lane] = (unsigned char)v; }
 };
 
 // ---- world-frame kinematics of the six joint frames (axis z_k, origin o_k) and of the two jaw links ------------------------
@@ -126,10 +136,13 @@ template <typename T> SO100_HD void contact_frame(const T n[3], T t1[3], T t2[3]
 
 // append one contact (returns false when the pad budget is exhausted).  vrel = relative point velocity geom2 - geom1.
 template <typename T, class Store>
-SO100_HD bool contact_add(Store& cs, int kind, const T p[3], const T n[3], T dist, const T vrel[3]) {
+SO100_HD bool contact_add(Store& cs, int kind, int id, const T p[3], const T n[3], T dist, const T vrel[3]) {
     if (kind != 0 && cs.n >= MAXPADC) { cs.dropped++; return false; }
     if (cs.n >= MAXC) { cs.dropped++; return false; }
     const int s = cs.n++;
+    int mask0 = 15;                                            // a new contact: expect all four edges to push (an impact sticks first)
+#pragma unroll 1
+    for (int k = 0; k < cs.prev_n; k++) { const int c = cs.getp(k); if ((c >> 4) == contact_id_hash(id)) mask0 = c & 15; }
     // impedance, reference and regulariser: R = 2 mu^2 (1 - imp)/imp * (1 + mu^2) * (translational invweight0 of both bodies), mu = 1
     T imp, K, B, tran;
     if (kind == 0) { imp = impedance(tabs(dist)); K = T(so100g::SOLREF_K); B = T(so100g::SOLREF_B); tran = T(1.0/so100g::CUBE_MASS); }
@@ -141,7 +154,7 @@ SO100_HD bool contact_add(Store& cs, int kind, const T p[3], const T n[3], T dis
     const T R = T(4)*tran*(T(1) - imp)*trcp(imp);
     cs.set(s, C_PX, p[0]); cs.set(s, C_PY, p[1]); cs.set(s, C_PZ, p[2]);
     cs.set(s, C_NX, n[0]); cs.set(s, C_NY, n[1]); cs.set(s, C_NZ, n[2]);
-    cs.set(s, C_KD, K*imp*dist); cs.set(s, C_RINV, trcp(R)); cs.set(s, C_KIND, T(kind));
+    cs.set(s, C_KD, K*imp*dist); cs.set(s, C_RINV, trcp(R)); cs.set(s, C_KIND, T(kind | (id << 3) | (mask0 << 11)));
     cs.set(s, C_VX, B*vrel[0]); cs.set(s, C_VY, B*vrel[1]); cs.set(s, C_VZ, B*vrel[2]);
     return true;
 }
@@ -156,7 +169,7 @@ template <typename T> SO100_HD void cube_point_motion(const T Rc[9], const T cpo
 
 // ---- narrowphase -----------------------------------------------------------------------------------------------------------
 // mjc_PlaneBox against the floor z = 0: corners at / below the plane and below the box centre, in corner order, at most 4.
-// R row-major, world <- box.  `emit(p, dist)` is called per contact.
+// R row-major, world <- box.  `emit(p, dist, corner)` is called per contact.
 template <typename T, class Emit>
 SO100_HD void plane_box(const T c[3], const T R[9], const T h[3], Emit emit) {
     int cnt = 0;
@@ -167,7 +180,7 @@ SO100_HD void plane_box(const T c[3], const T R[9], const T h[3], Emit emit) {
         if (!(c[2] + lz > T(0) || lz > T(0)) && cnt < 4) {
             const T dist = c[2] + lz;
             const T p[3] = { R[0]*v0 + R[1]*v1 + R[2]*v2 + c[0], R[3]*v0 + R[4]*v1 + R[5]*v2 + c[1], lz + c[2] - T(0.5)*dist };
-            emit(p, dist);
+            emit(p, dist, k);
             cnt++;
         }
     }
@@ -346,7 +359,7 @@ SO100_HD int box_box(const T cA[3], const T RA[9], const T hA[3], const T cB[3],
 // Returns true when at least one pad/cube contact exists.
 template <typename T, class Store>
 SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<T>& cube, const T Rc[9], unsigned flags, bool cube_live, Store& cs) {
-    cs.n = 0; cs.dropped = 0;
+    cs.n = 0; cs.dropped = 0;                                 // (cs.prev_n / the previous list stay: contact_add looks the new contacts up in it)
     Spatial<T> V4, V5;
     link_spatial(W, v, V4, V5);
     const T nz[3] = { T(0), T(0), T(1) };
@@ -385,9 +398,9 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             const T c[3] = { o[0] + R[0]*pp[0] + R[1]*pp[1] + R[2]*pp[2], o[1] + R[3]*pp[0] + R[4]*pp[1] + R[5]*pp[2], o[2] + R[6]*pp[0] + R[7]*pp[1] + R[8]*pp[2] };
             if (pass == 0) {
                 if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) {
-                    plane_box<T>(c, R, h, [&](const T* p, T dist) {
+                    plane_box<T>(c, R, h, [&](const T* p, T dist, int corner) {
                         T vr[3]; point_motion(pick_spatial(l5, V4, V5), p, vr);
-                        contact_add(cs, l5 ? 2 : 1, p, nz, dist, vr);
+                        contact_add(cs, l5 ? 2 : 1, 8*g + corner, p, nz, dist, vr);
                     });
                 }
             } else {
@@ -397,10 +410,11 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
                     // the points are emitted before the normal is returned: records are appended with a placeholder, then patched
                     const int s0 = cs.n;
                     T nrm[3];
+                    int slot = 0;
                     const int k = box_box<T>(c, R, h, cube.pos, Rc, hc, nrm, [&](const T* p, T dist) {
                         T va[3], vc[3]; point_motion(pick_spatial(l5, V4, V5), p, va); cube_point_motion(Rc, cube.pos, cube.vel, p, vc);
                         const T vr[3] = { vc[0] - va[0], vc[1] - va[1], vc[2] - va[2] };
-                        contact_add(cs, l5 ? 4 : 3, p, nz, dist, vr);
+                        contact_add(cs, l5 ? 4 : 3, 64 + 8*g + (slot++ & 7), p, nz, dist, vr);
                     });
                     coupled = coupled || k > 0;
                     for (int s = s0; s < cs.n; s++) { cs.set(s, C_NX, nrm[0]); cs.set(s, C_NY, nrm[1]); cs.set(s, C_NZ, nrm[2]); }
@@ -409,11 +423,12 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
         }
     }
     if (coupled && (flags & F_FLOOR) != 0u) {
-        plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist) {
+        plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist, int corner) {
             T vr[3]; cube_point_motion(Rc, cube.pos, cube.vel, p, vr);
-            contact_add(cs, 0, p, nz, dist, vr);
+            contact_add(cs, 0, 128 + corner, p, nz, dist, vr);
         });
     }
+    if (cs.n > 0) cs.prev_n = cs.n;                            // (the solve fills the list: every row pass leaves id | final mask per record)
     return coupled;
 }
 
@@ -466,16 +481,24 @@ template <typename T> SO100_HD void ldl6_reconstruct(const T L[21], T M[21]) {
 // ---- the primal problem of one env's substep ----------------------------------------------------------------------------
 // ND = 6: arm only (pad/floor contacts);  ND = 12: arm + cube (a pad touches the cube): x = [arm qacc (6) ; cube qacc (6)]
 template <int ND, typename T, class Store> struct PrimalProblem {
-    const WorldFK<T>& W; const Store& cs;
+    const WorldFK<T>& W; Store& cs;
     const T* Marm;             // packed lower 6x6
     const T* tau;              // arm smooth force
     const ArmRows<T>& rows;    // friction / limit row constants
     const T* Rc; const T* cpos; const T* a0c;      // cube rotation (world <- body), centre, smooth linear acceleration (ND = 12)
+    int* zones;                // active-set memory of the arm's own rows: per joint 3 bits (friction 0 quadratic / 1 low / 2 high, limit active)
     static constexpr int NH = ND*(ND + 1)/2;
 
-    // cost at x; MODE 0: cost only, 1: + gradient, 2: + Hessian
-    template <int MODE> SO100_HD T eval(const T x[ND], T g[ND], T H[NH]) const {
+    // cost at x; MODE 0: cost only, 1: + gradient, 2: + Hessian.
+    // FORCED: gradient and Hessian of the QUADRATIC whose active set is the remembered one (*zones, the records' mask0) instead of
+    // the one x selects: its minimiser is the solution whenever the active set did not change since the previous substep.
+    // A plain MODE 2 pass records the active set it saw (*zones, the records' mask, the store's previous list) and reports in
+    // `same` whether that is the set of the quadratic that produced x (the remembered one): if it is, and x is that quadratic's
+    // minimiser (a full Newton step), x minimises the true cost -- the piecewise-quadratic problem's exact convergence test.
+    template <int MODE, bool FORCED = false> SO100_HD T eval(const T x[ND], T g[ND], T H[NH], bool* same = nullptr) const {
         T cost = T(0);
+        const int zin = *zones;
+        int zout = 0, differ = 0;
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < NH; i++) H[i] = T(0);
@@ -507,19 +530,23 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             const T F = rows.fmax_[i];
             if (F > T(0)) {
                 const T R = rows.Rf[i], D = trcp(R), jar = x[i] + rows.cfv[i];
-                if (jar <= -R*F)     { cost += -T(0.5)*R*F*F - F*jar; if (MODE >= 1) g[i] -= F; }
-                else if (jar >= R*F) { cost += -T(0.5)*R*F*F + F*jar; if (MODE >= 1) g[i] += F; }
+                const int zone = FORCED ? ((zin >> (3*i)) & 3) : (jar <= -R*F ? 1 : jar >= R*F ? 2 : 0);
+                if (zone == 1)      { cost += -T(0.5)*R*F*F - F*jar; if (MODE >= 1) g[i] -= F; }
+                else if (zone == 2) { cost += -T(0.5)*R*F*F + F*jar; if (MODE >= 1) g[i] += F; }
                 else { cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D; }
+                zout |= zone << (3*i);
             }
             const T sg = rows.sg[i];
             if (sg != T(0)) {
                 const T jar = sg*x[i] + rows.clv[i];
-                if (jar < T(0)) {
+                if (FORCED ? ((zin >> (3*i + 2)) & 1) != 0 : jar < T(0)) {
                     const T D = trcp(rows.Rl[i]);
                     cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += sg*D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D;
+                    zout |= 4 << (3*i);
                 }
             }
         }
+        if (MODE == 2 && !FORCED) { differ = zout ^ zin; *zones = zout; }
         // contacts
         Spatial<T> S4, S5;
         link_spatial(W, x, S4, S5);
@@ -528,7 +555,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         for (int s = 0; s < cs.n; s++) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
-            const int kind = (int)cs.get(s, C_KIND);
+            const int code = (int)cs.get(s, C_KIND), kind = code & 7;
             // ND == 6 (arm alone): every record is a pad/floor contact, whose frame is made of world axes (mju_makeFrame of +z:
             // n = e_z, t1 = e_y, t2 = -e_x): projections on the frame are component picks
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
@@ -540,9 +567,18 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             if (ND == 12 && cube_side) { T ac[3]; cube_point_motion(Rc, cpos, x + 6, p, ac); w[0] += ac[0]; w[1] += ac[1]; w[2] += ac[2]; }
             const T jn = (ND == 6 ? w[2] : dot(n, w)) + kd, j1 = ND == 6 ? w[1] : dot(t1, w), j2 = ND == 6 ? -w[0] : dot(t2, w);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 };        // edges n +- mu t1, n +- mu t2 (mu = 1)
-            T m_[4];
+            T m_[4]; bool act[4]; int mask = 0;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { m_[e] = jar[e] < T(0) ? jar[e] : T(0); cost += T(0.5)*D*m_[e]*m_[e]; }
+            for (int e = 0; e < 4; e++) {
+                act[e] = FORCED ? ((code >> (11 + e)) & 1) != 0 : jar[e] < T(0);
+                m_[e] = act[e] ? jar[e] : T(0); cost += T(0.5)*D*m_[e]*m_[e];
+                mask |= act[e] ? 1 << e : 0;
+            }
+            if (MODE == 2 && !FORCED) {
+                differ |= mask ^ ((code >> 11) & 15);
+                cs.set(s, C_KIND, T((code & 2047) | (mask << 11)));
+                cs.setp(s, (contact_id_hash((code >> 3) & 255) << 4) | mask);
+            }
             if (MODE >= 1) {
                 const T cn = D*(m_[0] + m_[1] + m_[2] + m_[3]), c1 = D*(m_[0] - m_[1]), c2 = D*(m_[2] - m_[3]);
                 T Fv[3] = { -c2, c1, cn };
@@ -586,7 +622,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 }
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
-                    const T De = jar[e] < T(0) ? D : T(0);
+                    const T De = act[e] ? D : T(0);
                     T J[ND];
 #pragma unroll
                     for (int i = 0; i < ND; i++) J[i] = cn_[i] + (e == 0 ? c1_[i] : e == 1 ? -c1_[i] : e == 2 ? c2_[i] : -c2_[i]);
@@ -609,6 +645,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 g[i] += W.z[i][0]*(Ta[0] - oxf[0]) + W.z[i][1]*(Ta[1] - oxf[1]) + W.z[i][2]*(Ta[2] - oxf[2]);
             }
         }
+        if (MODE == 2 && !FORCED && same) *same = differ == 0;
         return cost;
     }
 
@@ -656,7 +693,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         for (int s = 0; s < cs.n; s++) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
-            const int kind = (int)cs.get(s, C_KIND);
+            const int kind = (int)cs.get(s, C_KIND) & 7;
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
             if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
             const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
@@ -682,7 +719,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 };
 
 #if !defined(__HIPCC__)
-static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0;     // host-only instrumentation
+static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0;     // host-only instrumentation
 static int g_dbg_cnewton_trace = 0;
 #endif
 #if defined(SO100_CONTACT_STATS) && defined(__HIPCC__)
@@ -690,6 +727,8 @@ __device__ unsigned long long so100_cstats[8];          // calls, iterations, li
 #endif
 #if defined(SO100_CONTACT_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define SO100_CSTAT(i) atomicAdd(&so100_cstats[i], 1ull)
+#elif !defined(__HIPCC__)
+#define SO100_CSTAT(i) ((i) == 3 || (i) == 2 ? (void)g_dbg_cnewton_passes++ : (void)0)
 #else
 #define SO100_CSTAT(i) ((void)0)
 #endif
@@ -718,7 +757,7 @@ template <int ND, typename T> SO100_HD T grad_merit(const T g[ND]) {
 }
 
 template <int ND, typename T, class Store>
-SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND]) {
+SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND], bool warm, int* work = nullptr) {
     constexpr int NH = ND*(ND + 1)/2;
     const bool f32 = sizeof(T) == 4;
     T last = T(0);
@@ -726,9 +765,31 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
     g_dbg_cnewton_calls++;
 #endif
     T g[ND], H[NH];
-    P.template eval<2>(x, g, H);
+    if (warm) {
+        // Active-set warm start.  The rows are stiff (a force-carrying row sits at jar = -R f, a hair below zero), so the sign of jar at
+        // the previous acceleration says nothing about which rows will carry force now -- the previous substep's final active set does.
+        // One step on the quadratic of THAT set lands on the solution whenever the set did not change (the usual case in sustained
+        // contact); the plain iteration below starts from there, verifies, and repairs the set where it did change.
+        T Dinv[ND], dx[ND];
+        P.template eval<2, true>(x, g, H);
+        if (work) *work += 1;
+        SO100_CSTAT(3);
+#pragma unroll
+        for (int i = 0; i < ND; i++) dx[i] = -g[i];
+        ldln<ND>(H, Dinv);
+        ldln_solve<ND>(H, Dinv, dx);
+#pragma unroll
+        for (int i = 0; i < ND; i++) x[i] += dx[i];
+    }
+    bool same = false;
+    P.template eval<2>(x, g, H, &same);
+    if (work) *work += 1;
     SO100_CSTAT(0); SO100_CSTAT(3);
+    // onq: x came from a full Newton step on the quadratic of the very active set it selects, i.e. it IS the minimiser up to the
+    // round-off of that step; one more step on the same quadratic (iterative refinement) and the solve ends without a verifying pass
+    bool onq = warm && same;
     T E0 = grad_merit<ND>(g);
+    bool small_prev = false;                                  // the previous step was small and brought no progress in the merit
     for (int it = 0; it < iters; it++) {
         T Dinv[ND], dx[ND];
         SO100_CSTAT(1);
@@ -751,17 +812,8 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         if (g_dbg_cnewton_trace) printf("  it %d E %.3e g.dx %.3e dmax %.3e xmax %.3e\n", it, (double)E0, (double)gdx, (double)dmax, (double)xmax);
 #endif
         const T tol = (f32 ? T(1e-4) : T(1e-11))*(T(1) + T(0.01)*xmax);
-        if (dmax < tol) {                                     // converged: the step no longer changes the acceleration
-#pragma unroll
-            for (int i = 0; i < ND; i++) x[i] += dx[i];
-            last = T(0);
-            break;
-        }
-        if (f32 && ND == 6 && dmax < T(1e-3)*(T(1) + xmax)) {
-            // A small step from a good warm start (the usual case in sustained contact: the solution moves by a few per cent per
-            // substep; here: below 0.1 per cent, arm-only problem: the 8 g cube of the coupled one is too sensitive) is taken as it stands: the quadratic model it minimises is exact unless a row changes zone along it, and
-            // then the error is a fraction of this small step, which the next substep's solve -- warm-started here -- removes.
-            // (The verifying evaluation would double the cost of every substep in contact.)
+        const bool small = dmax < (f32 ? T(1e-3) : T(1e-10))*(T(1) + xmax);
+        if (dmax < tol || onq || (small_prev && small)) {     // converged: the step no longer changes the acceleration
 #pragma unroll
             for (int i = 0; i < ND; i++) x[i] += dx[i];
             last = T(0);
@@ -771,21 +823,29 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         T xn[ND], gn[ND];
 #pragma unroll
         for (int i = 0; i < ND; i++) xn[i] = x[i] + dx[i];
-        P.template eval<2>(xn, gn, H);                        // gradient + Hessian at the trial point: next iteration's, if accepted
+        P.template eval<2>(xn, gn, H, &same);                 // gradient + Hessian at the trial point: next iteration's, if accepted
+        if (work) *work += 1;
         SO100_CSTAT(3);
+        if (same) {                                           // the full step stayed on its quadratic: the minimiser, up to round-off
+#pragma unroll
+            for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
+            onq = true; last = T(0);
+            continue;
+        }
         const T E1 = grad_merit<ND>(gn);
         T d1 = T(0);
 #pragma unroll
         for (int i = 0; i < ND; i++) d1 += gn[i]*dx[i];
         const bool progress = E1 <= T(0.25)*E0;
-        if (!progress && dmax < (f32 ? T(1e-3) : T(1e-10))*(T(1) + xmax)) {   // working precision reached (see above)
-            if (E1 <= E0) {
+        if (!progress && small) {
+            // Either working precision is reached (see above) or x sits at a kink whose other side wants to go elsewhere: the
+            // next step tells -- a second small one ends the solve, a large one carries on from the trial point.
 #pragma unroll
-                for (int i = 0; i < ND; i++) x[i] = xn[i];
-            }
-            last = T(0);
-            break;
+            for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
+            E0 = E1; small_prev = true;
+            continue;
         }
+        small_prev = false;
         if (progress || d1 <= T(0.5)*tabs(gdx)) {
 #pragma unroll
             for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
@@ -798,6 +858,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll 1
         for (int ls = 0; ls < (f32 ? (ND == 12 ? 6 : SO100_LS_PASSES) : 40); ls++) {      // (the coupled problem with its 8 g cube needs the better minimiser)
             P.line_deriv(x, dx, alpha, d1, d2);
+            if (work) *work += 1;
             SO100_CSTAT(2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
@@ -815,9 +876,13 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += alpha*dx[i];
         P.template eval<2>(x, g, H);
+        if (work) *work += 1;
         SO100_CSTAT(3);
         E0 = grad_merit<ND>(g);
     }
+#if !defined(__HIPCC__)
+    if (g_dbg_cnewton_trace) { printf("     x ="); for (int i = 0; i < ND; i++) printf(" %.5g", (double)x[i]); printf("  zones %x onq %d\n", *P.zones, (int)onq); }
+#endif
     return last;
 }
 
@@ -827,21 +892,32 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 // cube together with the arm (cs then holds its floor contacts too); cwarm = the cube's warm start in so100_cube.hpp's
 // convention (qacc - qacc_smooth), xcube = its acceleration out.  Returns the solver residual (0 when converged).
 template <typename T, class Store>
-SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], const WorldFK<T>& W, const Store& cs, bool coupled,
-                         const T cpos[3], const T cwarm[6], const T Rc[9], const T applied[3], int iters, T acc[6], T xcube[6]) {
+SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], const WorldFK<T>& W, Store& cs, bool coupled,
+                         const T cpos[3], const T cwarm[6], const T Rc[9], const T applied[3], int iters, T acc[6], T xcube[6], int* zones, int* work = nullptr) {
     const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
     T res;
+    if (*zones < 0) {                                          // no memory yet: the arm rows' zones at the warm-start acceleration, contacts all edges
+        int z = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const T F = r.fmax_[i];
+            if (F > T(0)) { const T jar = acc[i] + r.cfv[i]; z |= (jar <= -r.Rf[i]*F ? 1 : jar >= r.Rf[i]*F ? 2 : 0) << (3*i); }
+            if (r.sg[i] != T(0) && r.sg[i]*acc[i] + r.clv[i] < T(0)) z |= 4 << (3*i);
+        }
+        *zones = z;
+    }
+    const bool warm = true;
     if (!coupled) {
-        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c };
-        res = primal_newton<6>(P, iters, acc);
+        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
+        res = primal_newton<6>(P, iters, acc, warm, work);
     } else {
-        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c };
+        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
         T x[12];
 #pragma unroll
         for (int i = 0; i < 6; i++) x[i] = acc[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) { x[6 + i] = cwarm[i] + a0c[i]; x[9 + i] = cwarm[3 + i]; }
-        res = primal_newton<12>(P, iters, x);
+        res = primal_newton<12>(P, iters, x, warm, work);
 #pragma unroll
         for (int i = 0; i < 6; i++) { acc[i] = x[i]; xcube[i] = x[6 + i]; }
     }
@@ -854,8 +930,8 @@ SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], 
 // coupled: the cube is solved with the arm and integrated here.
 template <typename T, class Store>
 SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], unsigned flags, int iters,
-                                      Arm<T>& A, const WorldFK<T>& W, const Store& cs, bool coupled, Cube<T>& cube, const T Rc[9],
-                                      const T applied[3], T dq[6], T* residual) {
+                                      Arm<T>& A, const WorldFK<T>& W, Store& cs, bool coupled, Cube<T>& cube, const T Rc[9],
+                                      const T applied[3], T dq[6], T* residual, int* zones) {
     T tau[6], acc[6], xcube[6];
     arm_tau(q, v, ctrl, A, tau);
     ArmRows<T> r;
@@ -864,7 +940,7 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
     ldl6_reconstruct(A.M, Marm);
 #pragma unroll
     for (int i = 0; i < 6; i++) acc[i] = aw[i];
-    const T res = contact_solve(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube);
+    const T res = contact_solve(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones);
     if (coupled) {
         // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
         const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
@@ -882,9 +958,11 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
 
 // One whole substep of one env with the pad-contact flags on, single lane (the one-wave step kernel and the host tests; the
 // multi-wave kernels run the same stages spread over their waves).  stat (optional): [0] contacts, [1] coupled, [2] dropped.
+// cs / zones: the caller's contact store and active-set memory, kept from substep to substep (zones = -1 to start with).
 template <typename T>
 SO100_HD void substep_with_pads(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], Cube<T>& cube, const T applied[3],
-                                unsigned flags, int solver_iters, int contact_iters, Arm<T>& A, bool first, T dq[6], T* residual, int* stat = nullptr) {
+                                unsigned flags, int solver_iters, int contact_iters, Arm<T>& A, bool first, T dq[6], T* residual,
+                                ContactsPriv<T>& cs, int& zones, int* stat = nullptr) {
     if (first) arm_trig(q, A); else arm_trig_update(q, dq, A);
     arm_bias(v, A);
     arm_mass(A);
@@ -895,11 +973,10 @@ SO100_HD void substep_with_pads(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6
     T qn[4] = { cube.quat[0], cube.quat[1], cube.quat[2], cube.quat[3] };
     quat_normalize(qn);
     T Rc[9]; quat_to_mat(qn, Rc);
-    ContactsPriv<T> cs;
     const bool coupled = detect_pad_contacts(W, v, cube, Rc, flags, cube_live, cs);
     if (stat) { stat[0] = cs.n; stat[1] = coupled ? 1 : 0; stat[2] = cs.dropped; }
     if (cs.n > 0) {
-        contact_solve_integrate(q, v, qc, ctrl, ff, fl, aw, flags, contact_iters, A, W, cs, coupled, cube, Rc, applied, dq, residual);
+        contact_solve_integrate(q, v, qc, ctrl, ff, fl, aw, flags, contact_iters, A, W, cs, coupled, cube, Rc, applied, dq, residual, &zones);
         if (!coupled) cube_substep(cube, applied, flags, contact_iters);
     } else {
         arm_solve_integrate(q, v, qc, ctrl, ff, fl, flags, solver_iters, A, dq, residual, aw);

@@ -111,6 +111,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     __shared__ float xa[PADS ? 14 : 1][64];
     __shared__ float xk[PADS ? 12 : 1][64];
     __shared__ float xm[PADS ? 21 : 1][64];
+    __shared__ unsigned char pbuf[PADS ? MAXC*64 : 1];
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -129,8 +130,9 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
         env_step_pre<KIND>(e, a, u, p, ctx);
     }
     Arm<float> A; Prof prof_;
-    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm };
-    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [](int) {}, [&]() {
+    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm, pbuf };
+    ContactMemo memo;                                             // (one env step per launch: the memory lives for its 16 substeps)
+    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [](int) {}, [&]() {
         ctx = StepCtx{};
 #pragma unroll
         for (int k = 0; k < 8; k++) u[k] = 0.0f;
@@ -211,11 +213,16 @@ template <int KIND> struct KindOps {
     static hipError_t rollout(const SimParams& prm, float* state, const float* start_tab, const RolloutPtrs& io, const PolicyWeights& pw, const RolloutArgs& ra, hipStream_t st);
 #ifdef SO100_ROLLOUT_PROF
     static int prof_read(long long* out48);       // the cycle counters live in the kind's own code object
+    static int prof_read_wg(long long* wg4096, int* env32768);
 #endif
 };
 #ifdef SO100_ROLLOUT_PROF
 template <int KIND> int KindOps<KIND>::prof_read(long long* out48) {
     return hipMemcpyFromSymbol(out48, HIP_SYMBOL(so100_prof), sizeof(long long)*48) == hipSuccess ? 0 : -1;
+}
+template <int KIND> int KindOps<KIND>::prof_read_wg(long long* wg, int* env) {
+    if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(so100_prof_wg), sizeof(long long)*4096) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(env, HIP_SYMBOL(so100_prof_env), sizeof(int)*32768) == hipSuccess ? 0 : -1;
 }
 #endif
 

@@ -32,16 +32,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // -DSO100_ROLLOUT_PROF; the product library compiles these to nothing).  Slots: see tools/rollout_prof.py.
 #ifdef SO100_ROLLOUT_PROF
 __device__ long long so100_prof[48];
+__device__ long long so100_prof_wg[1024*4];    // per workgroup: wave 0 total, wave 3 narrowphase, wave 3 contact Newton, wave 0 barrier-3 wait
+__device__ int so100_prof_env[16384*2];        // per env: row passes of the contact Newton, substeps with a pad contact (this launch)
 struct Prof {
     long long t[10] = {}, c = __builtin_readcyclecounter();
+    int work = 0, insub = 0;
     __device__ __forceinline__ void mark(int slot) { const long long n = __builtin_readcyclecounter(); t[slot] += n - c; c = n; }
     __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 10; i++) so100_prof[base + i] = t[i]; }
+    __device__ __forceinline__ void flush_wg(int wave, int lane, int env, bool live) const {
+        if (blockIdx.x < 1024 && lane == 0) {
+            long long tot = 0; for (int i = 0; i < 10; i++) tot += t[i];
+            if (wave == 0) { so100_prof_wg[blockIdx.x*4 + 0] = tot; so100_prof_wg[blockIdx.x*4 + 3] = t[8]; }
+            if (wave == 3) { so100_prof_wg[blockIdx.x*4 + 1] = t[4]; so100_prof_wg[blockIdx.x*4 + 2] = t[6]; }
+        }
+        if (wave == 3 && live && env < 16384) { so100_prof_env[2*env] = work; so100_prof_env[2*env + 1] = insub; }
+    }
 };
+#define SO100_PROF_WORK (&prof_.work)
+#define SO100_PROF_INSUB() (prof_.insub++)
 #else
 struct Prof {
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush(int, bool) const {}
+    __device__ __forceinline__ void flush_wg(int, int, int, bool) const {}
 };
+#define SO100_PROF_WORK nullptr
+#define SO100_PROF_INSUB() ((void)0)
 #endif
 #define SO100_PROF_DECL Prof prof_;
 #define SO100_PROF(slot) prof_.mark(slot)
@@ -72,7 +88,10 @@ struct Prof {
 // acceleration (0-5) and cube acceleration (6-11) of the contact wave's solve, contact code (12: count | coupled << 8 |
 // dropped << 16), solver residual (13).
 // xm [21][64] = the arm's mass matrix (packed lower, unfactored), published by wave 0 before it factorises it in place.
-struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; };
+struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; unsigned char* pbuf; };
+// the contact wave's active-set memory (so100_contact.hpp: primal_newton), kept by the caller from env step to env step:
+// zones = the arm rows' zones of the last contact solve (-1: none yet), prev_n = length of the (id | mask) list in L.pbuf
+struct ContactMemo { int zones = -1, prev_n = 0; };
 
 // Register pressure.  The kernel is ONE control-flow graph: whatever another wave will read later (wave 0's env state `e`, its
 // mass-matrix factor A, wave 2's cube block) is live across the contact wave's Newton as far as the register allocator can
@@ -81,7 +100,7 @@ struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf
 // Newton to a use passes that definition, so the old values are dead during the solve and their registers are free.
 template <bool PADS, class Hook, class Forget>
 __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, float ctrl[6], float cstale[3],
-                                                 Arm<float>& A, const PhaseLds& L, Prof& prof_, Hook after_first_barrier, Forget forget_caller_state) {
+                                                 Arm<float>& A, const PhaseLds& L, ContactMemo& memo, Prof& prof_, Hook after_first_barrier, Forget forget_caller_state) {
     float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk; float (*xm)[64] = L.xm;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
@@ -156,7 +175,8 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         SO100_PROF(3);                                     // barrier 1 wait
         after_first_barrier(sub);
         // ---- first half of the substep: everything that does not need the other waves' results
-        WorldFK<float> W3; Arm<float> A3; ContactsLds<float> cs3{ L.cbuf, lane };     // contact wave only
+        WorldFK<float> W3; Arm<float> A3; ContactsLds<float> cs3{ L.cbuf, lane, L.pbuf };     // contact wave only
+        cs3.prev_n = memo.prev_n;
         float Rc3[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f }, cpos3[3] = { 0.0f, 0.0f, 0.0f };
         bool coupled3 = false, any3 = false;
         if (wave == 1) {
@@ -198,6 +218,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                 quat_normalize(qn); quat_to_mat(qn, Rc3);
             }
             coupled3 = detect_pad_contacts<float>(W3, v3, c3b, Rc3, p.flags, padcube, cs3);
+            memo.prev_n = cs3.prev_n;
             xa[12][lane] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
             any3 = __any(cs3.n > 0);
             SO100_PROF(4);                                 // FK + narrowphase (wave 3)
@@ -240,7 +261,8 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                     for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][lane];
                     ap3[2] = xc[19][lane];
                 }
-                const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube);
+                const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube, &memo.zones, SO100_PROF_WORK);
+                SO100_PROF_INSUB();
 #pragma unroll
                 for (int i = 0; i < 6; i++) { xa[i][lane] = x3[i]; xa[6 + i][lane] = xcube[i]; aw3[i] = x3[i]; }
                 xa[13][lane] = res;
@@ -477,6 +499,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     __shared__ float xq[PADS ? 24 : 18][64];                      // physics split: sin q, cos q, v (+ q) of env = lane (wave 0 -> waves 1, 3)
     __shared__ float xc[24][64];                                  //                cube state hand-over (wave 0 <-> wave 2)
     __shared__ float xb[6][64];                                   //                bias force          (wave 1 -> wave 0)
+    __shared__ unsigned char pbuf[PADS ? MAXC*64 : 1];            // pad contacts: (feature hash | edge mask) per record of the last solve
+    ContactMemo memo;                                             // ... and the rest of the contact wave's active-set memory
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -617,8 +641,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
         {
             Arm<float> A;
-                        const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm };
-            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, prof_, [&](int sub) {
+                        const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm, pbuf };
+            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
                     policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
@@ -662,6 +686,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         __syncthreads();
     }
     SO100_PROF_FLUSH(10*wave);
+    prof_.flush_wg(wave, lane, env, live);
     if (wave == 0 && live) {
         store_env_state<KIND, FL>(state, p.n, env, e);
         if (ra.T > 0) {

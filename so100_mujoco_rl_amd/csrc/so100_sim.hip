@@ -65,6 +65,7 @@ const char* so100_state_field_name(int32_t field) { return (field >= 0 && field 
 const char* so100_last_error(void) { return g_err; }
 #ifdef SO100_ROLLOUT_PROF
 int so100_prof_read(int kind, long long* out48) { return DISPATCH_KIND(kind, prof_read)(out48); }
+int so100_prof_read_wg(int kind, long long* wg4096, int* env32768) { return DISPATCH_KIND(kind, prof_read_wg)(wg4096, env32768); }
 #endif
 
 int so100_create(const so100_config* cfg, so100_sim** out) {

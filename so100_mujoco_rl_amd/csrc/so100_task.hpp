@@ -294,12 +294,13 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
     const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
     const bool pads = (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
     e.res = 0.0f; e.cstat = 0;
+    ContactsPriv<float> cs; int zones = -1;                  // the contact solve's active-set memory lives for this env step
 #pragma unroll 1
     for (int s = 0; s < p.frame_skip; s++) {
         cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
         if (pads) {
             int st[3];
-            substep_with_pads<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, e.cube, applied, p.flags, p.solver_iters, p.contact_iters, A, s == 0, dq, &e.res, st);
+            substep_with_pads<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, e.cube, applied, p.flags, p.solver_iters, p.contact_iters, A, s == 0, dq, &e.res, cs, zones, st);
             const int n = e.cstat & 255, dr = e.cstat >> 8;
             e.cstat = (st[0] > n ? st[0] : n) | ((dr + st[2] > 0xFFFF ? 0xFFFF : dr + st[2]) << 8);
         } else {

@@ -64,10 +64,11 @@ template <typename T> static void csub(double* st, const double* ctrl, const dou
     for (int i = 0; i < 4; i++) cb.quat[i] = (T)st[33+i];
     for (int i = 0; i < 6; i++) { cb.vel[i] = (T)st[37+i]; cb.warm[i] = (T)st[43+i]; }
     Arm<T> A; T dq[6] = {0,0,0,0,0,0}; T res = T(0);
+    ContactsPriv<T> cs; int zones = -1;
     stat[0] = stat[1] = stat[2] = stat[3] = 0;
     for (int s = 0; s < n; s++) {
         int sst[3];
-        substep_with_pads<T>(q, v, qc, cc, ff, fl, aw, cb, ap, flags, iters, citers, A, (s % 16) == 0, dq, &res, sst);
+        substep_with_pads<T>(q, v, qc, cc, ff, fl, aw, cb, ap, flags, iters, citers, A, (s % 16) == 0, dq, &res, cs, zones, sst);
         for (int k = 0; k < 3; k++) stat[k] = sst[k] > stat[k] ? sst[k] : stat[k];
     }
     stat[3] = (int)(res*1e9 > 2e9 ? 2e9 : res*1e9);
@@ -92,6 +93,7 @@ int hc_boxbox_d(const double* cA, const double* RA, const double* hA, const doub
 int hc_boxbox_f(const double* cA, const double* RA, const double* hA, const double* cB, const double* RB, const double* hB, double* pos, double* nrm, double* dist) { return bb<float>(cA, RA, hA, cB, RB, hB, pos, nrm, dist); }
 void hc_cdbg_trace(int on) { g_dbg_cnewton_trace = on; }
 void hc_cdbg_counters(long* out) { out[0] = g_dbg_cnewton_calls; out[1] = g_dbg_cnewton_iters; out[2] = g_dbg_cnewton_ls; }
+long hc_cdbg_passes(void) { return g_dbg_cnewton_passes; }
 }
 
 // ---- the full task layer (so100_task.hpp) on the host, fp32, one env ------------------------------------------------

@@ -52,3 +52,24 @@ for w in range(4):
     for nm, x in zip(names, v):
         per = "  (%.0f / substep)" % (x / T / 16) if nm.split()[0] in ("trig", "barrier-1", "phase", "barrier-2", "barrier-3", "integrate") else ""
         print(f"    {nm:84s} {x / T:9.0f} ticks/step  {100.0 * x / max(tot, 1):5.1f} %{per}")
+
+# per-workgroup totals (the launch ends with its slowest workgroup) and per-env Newton work of the last launch
+import numpy as np
+wg = (C.c_longlong * 4096)(); envw = (C.c_int * 32768)()
+sim.L.so100_prof_read_wg.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+if sim.L.so100_prof_read_wg(1, wg, envw) == 0:
+    epw = 16 if flags & 4 else 64
+    nwg = (n + epw - 1)//epw
+    W = np.array(wg[:4*nwg], dtype=np.float64).reshape(nwg, 4)/T
+    E = np.array(envw[:2*n]).reshape(n, 2)
+    tot = W[:, 0]
+    print(f"# per workgroup ({nwg} x {epw} envs), ticks/step: total min {tot.min():.0f}  median {np.median(tot):.0f}  p90 {np.percentile(tot, 90):.0f}  max {tot.max():.0f}")
+    print(f"#   narrowphase (w3): median {np.median(W[:,1]):.0f} max {W[:,1].max():.0f};  contact Newton (w3): median {np.median(W[:,2]):.0f} p90 {np.percentile(W[:,2],90):.0f} max {W[:,2].max():.0f};  w0 barrier-3 wait: median {np.median(W[:,3]):.0f} max {W[:,3].max():.0f}")
+    order = np.argsort(-tot)
+    for b in list(order[:6]) + list(order[len(order)//2:len(order)//2 + 2]):
+        ev = E[b*epw:(b + 1)*epw]
+        act = ev[ev[:, 1] > 0]
+        print(f"#   wg {b:4d}: total {tot[b]:8.0f}  newton {W[b,2]:8.0f}  envs with contact {len(act):2d}/{epw}  substeps in contact (of {T*16}) {sorted(act[:,1].tolist(), reverse=True)[:6]}  row passes per contact substep {[round(a/max(b_,1),2) for a, b_ in sorted(act.tolist(), key=lambda r: -r[1])[:6]]}")
+    insub = E[:, 1].sum(); work = E[:, 0].sum()
+    print(f"# all envs: {100.0*insub/(n*T*16):.1f} % of env-substeps in pad contact, {work/max(insub,1):.2f} row passes per contact substep; per-wg sum over envs of row passes: median {np.median(E[:,0].reshape(nwg, epw).sum(1)):.0f} max {E[:,0].reshape(nwg, epw).sum(1).max():.0f};"
+          f" per-wg MAX-lane passes: median {np.median(E[:,0].reshape(nwg, epw).max(1)):.0f} max {E[:,0].reshape(nwg, epw).max(1).max():.0f}")
