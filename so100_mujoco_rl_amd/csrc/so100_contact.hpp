@@ -489,14 +489,13 @@ template <int ND, typename T, class Store> struct PrimalProblem {
     int* zones;                // active-set memory of the arm's own rows: per joint 3 bits (friction 0 quadratic / 1 low / 2 high, limit active)
     static constexpr int NH = ND*(ND + 1)/2;
 
-    // cost at x; MODE 0: cost only, 1: + gradient, 2: + Hessian.
+    // MODE 1: gradient at x, 2: + Hessian.  (The cost VALUE is never formed: no step of the solver compares costs, see primal_newton.)
     // FORCED: gradient and Hessian of the QUADRATIC whose active set is the remembered one (*zones, the records' mask0) instead of
     // the one x selects: its minimiser is the solution whenever the active set did not change since the previous substep.
     // A plain MODE 2 pass records the active set it saw (*zones, the records' mask, the store's previous list) and reports in
     // `same` whether that is the set of the quadratic that produced x (the remembered one): if it is, and x is that quadratic's
     // minimiser (a full Newton step), x minimises the true cost -- the piecewise-quadratic problem's exact convergence test.
-    template <int MODE, bool FORCED = false> SO100_HD T eval(const T x[ND], T g[ND], T H[NH], bool* same = nullptr) const {
-        T cost = T(0);
+    template <int MODE, bool FORCED = false> SO100_HD void eval(const T x[ND], T g[ND], T H[NH], bool* same = nullptr) const {
         const int zin = *zones;
         int zout = 0, differ = 0;
         if (MODE == 2) {
@@ -511,46 +510,38 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             T t = T(0);
 #pragma unroll
             for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
-            cost += x[i]*(T(0.5)*t - tau[i]);
-            if (MODE >= 1) g[i] = t - tau[i];
+            g[i] = t - tau[i];
         }
         if (ND == 12) {
             const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const T dl = x[6 + i] - a0c[i], da = x[9 + i];
-                cost += T(0.5)*(m*dl*dl + I*da*da);
-                if (MODE >= 1) { g[6 + i] = m*dl; g[9 + i] = I*da; }
+                g[6 + i] = m*dl; g[9 + i] = I*da;
                 if (MODE == 2) { H[SO100_TRI(6 + i, 6 + i)] = m; H[SO100_TRI(9 + i, 9 + i)] = I; }
             }
         }
-        // friction-loss rows (Huber) and limit rows (one-sided) of the arm: J = +-e_i
+        // friction-loss rows (Huber) and limit rows (one-sided) of the arm: J = +-e_i.  Branch-free: the Huber gradient is the
+        // clamped quadratic's, absent rows have D = 0 (rows.Df / rows.Dl) -- 20 instructions per joint instead of 80 behind branches.
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const T F = rows.fmax_[i];
-            if (F > T(0)) {
-                const T R = rows.Rf[i], D = trcp(R), jar = x[i] + rows.cfv[i];
-                const int zone = FORCED ? ((zin >> (3*i)) & 3) : (jar <= -R*F ? 1 : jar >= R*F ? 2 : 0);
-                if (zone == 1)      { cost += -T(0.5)*R*F*F - F*jar; if (MODE >= 1) g[i] -= F; }
-                else if (zone == 2) { cost += -T(0.5)*R*F*F + F*jar; if (MODE >= 1) g[i] += F; }
-                else { cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D; }
-                zout |= zone << (3*i);
-            }
-            const T sg = rows.sg[i];
-            if (sg != T(0)) {
-                const T jar = sg*x[i] + rows.clv[i];
-                if (FORCED ? ((zin >> (3*i + 2)) & 1) != 0 : jar < T(0)) {
-                    const T D = trcp(rows.Rl[i]);
-                    cost += T(0.5)*D*jar*jar; if (MODE >= 1) g[i] += sg*D*jar; if (MODE == 2) H[SO100_TRI(i, i)] += D;
-                    zout |= 4 << (3*i);
-                }
-            }
+            const T F = rows.fmax_[i], D = rows.Df[i], fq = D*(x[i] + rows.cfv[i]);      // the quadratic zone's force
+            const int zone = FORCED ? ((zin >> (3*i)) & 3) : (F > T(0) ? (fq <= -F ? 1 : fq >= F ? 2 : 0) : 0);
+            const T fr = zone == 1 ? -F : zone == 2 ? F : fq;
+            if (MODE >= 1) g[i] += fr;
+            if (MODE == 2) H[SO100_TRI(i, i)] += zone == 0 ? D : T(0);
+            zout |= zone << (3*i);
+            const T sg = rows.sg[i], Dl = rows.Dl[i], jl = sg*x[i] + rows.clv[i];
+            const bool act = FORCED ? ((zin >> (3*i + 2)) & 1) != 0 : (Dl > T(0) && jl < T(0));
+            if (MODE >= 1) g[i] += act ? sg*Dl*jl : T(0);
+            if (MODE == 2) H[SO100_TRI(i, i)] += act ? Dl : T(0);
+            zout |= act ? 4 << (3*i) : 0;
         }
         if (MODE == 2 && !FORCED) { differ = zout ^ zin; *zones = zout; }
         // contacts
         Spatial<T> S4, S5;
         link_spatial(W, x, S4, S5);
-        T F4[3] = { T(0), T(0), T(0) }, T4[3] = { T(0), T(0), T(0) }, F5[3] = { T(0), T(0), T(0) }, T5[3] = { T(0), T(0), T(0) };
+        T F45[3] = { T(0), T(0), T(0) }, T45[3] = { T(0), T(0), T(0) }, F5[3] = { T(0), T(0), T(0) }, T5[3] = { T(0), T(0), T(0) };   // wrenches on links 4 + 5, on link 5
 #pragma unroll 1
         for (int s = 0; s < cs.n; s++) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
@@ -571,7 +562,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 act[e] = FORCED ? ((code >> (11 + e)) & 1) != 0 : jar[e] < T(0);
-                m_[e] = act[e] ? jar[e] : T(0); cost += T(0.5)*D*m_[e]*m_[e];
+                m_[e] = act[e] ? jar[e] : T(0);
                 mask |= act[e] ? 1 << e : 0;
             }
             if (MODE == 2 && !FORCED) {
@@ -585,8 +576,9 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 if (ND == 12) { Fv[0] = cn*n[0] + c1*t1[0] + c2*t2[0]; Fv[1] = cn*n[1] + c1*t1[1] + c2*t2[1]; Fv[2] = cn*n[2] + c1*t1[2] + c2*t2[2]; }
                 if (arm_side) {
                     T tq[3]; cross(p, Fv, tq);
-                    if (on5) { F5[0] += sgn*Fv[0]; F5[1] += sgn*Fv[1]; F5[2] += sgn*Fv[2]; T5[0] += sgn*tq[0]; T5[1] += sgn*tq[1]; T5[2] += sgn*tq[2]; }
-                    else     { F4[0] += sgn*Fv[0]; F4[1] += sgn*Fv[1]; F4[2] += sgn*Fv[2]; T4[0] += sgn*tq[0]; T4[1] += sgn*tq[1]; T4[2] += sgn*tq[2]; }
+                    const T w5 = on5 ? sgn : T(0);
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { F45[k] += sgn*Fv[k]; T45[k] += sgn*tq[k]; F5[k] += w5*Fv[k]; T5[k] += w5*tq[k]; }
                 }
                 if (ND == 12 && cube_side) {
                     const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
@@ -620,24 +612,20 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                     };
                     cube_cols(n, cn_); cube_cols(t1, c1_); cube_cols(t2, c2_);
                 }
+                // sum over the active edges e of D (cn +- c_k)(cn +- c_k)' = the 3 x 3 weight matrix of the edge set in the (n, t1, t2)
+                // basis: w_nn = sum, w_11 = a0 + a1, w_22 = a2 + a3, w_n1 = a0 - a1, w_n2 = a2 - a3 (w_12 = 0)
+                const T a0 = act[0] ? D : T(0), a1 = act[1] ? D : T(0), a2 = act[2] ? D : T(0), a3 = act[3] ? D : T(0);
+                const T w11 = a0 + a1, w22 = a2 + a3, wnn = w11 + w22, wn1 = a0 - a1, wn2 = a2 - a3;
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const T De = act[e] ? D : T(0);
-                    T J[ND];
+                for (int i = 0; i < ND; i++) {
+                    const T un = wnn*cn_[i] + wn1*c1_[i] + wn2*c2_[i], u1 = wn1*cn_[i] + w11*c1_[i], u2 = wn2*cn_[i] + w22*c2_[i];
 #pragma unroll
-                    for (int i = 0; i < ND; i++) J[i] = cn_[i] + (e == 0 ? c1_[i] : e == 1 ? -c1_[i] : e == 2 ? c2_[i] : -c2_[i]);
-#pragma unroll
-                    for (int i = 0; i < ND; i++) {
-                        const T dj = De*J[i];
-#pragma unroll
-                        for (int j = 0; j <= i; j++) H[SO100_TRI(i, j)] += dj*J[j];
-                    }
+                    for (int j = 0; j <= i; j++) H[SO100_TRI(i, j)] += un*cn_[j] + u1*c1_[j] + u2*c2_[j];
                 }
             }
         }
         if (MODE >= 1) {
             // contact wrenches -> joint space: g_i += z_i . (T - o_i x F), links >= i
-            const T F45[3] = { F4[0] + F5[0], F4[1] + F5[1], F4[2] + F5[2] }, T45[3] = { T4[0] + T5[0], T4[1] + T5[1], T4[2] + T5[2] };
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;
@@ -646,7 +634,6 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             }
         }
         if (MODE == 2 && !FORCED && same) *same = differ == 0;
-        return cost;
     }
 
     // derivatives of phi(alpha) = cost(x + alpha dx) at alpha: d1 = phi', d2 = phi'' (of the current active set).  phi' is
@@ -673,18 +660,12 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const T F = rows.fmax_[i];
-            if (F > T(0)) {
-                const T R = rows.Rf[i], D = trcp(R), jar = xa[i] + rows.cfv[i];
-                if (jar <= -R*F) d1 -= F*dx[i];
-                else if (jar >= R*F) d1 += F*dx[i];
-                else { d1 += D*jar*dx[i]; d2 += D*dx[i]*dx[i]; }
-            }
-            const T sg = rows.sg[i];
-            if (sg != T(0)) {
-                const T jar = sg*xa[i] + rows.clv[i];
-                if (jar < T(0)) { const T D = trcp(rows.Rl[i]); d1 += D*jar*sg*dx[i]; d2 += D*dx[i]*dx[i]; }
-            }
+            const T F = rows.fmax_[i], D = rows.Df[i], fq = D*(xa[i] + rows.cfv[i]);
+            const bool quad = fq > -F && fq < F;
+            d1 += tclamp(fq, -F, F)*dx[i]; d2 += quad ? D*dx[i]*dx[i] : T(0);
+            const T sg = rows.sg[i], Dl = rows.Dl[i], jl = sg*xa[i] + rows.clv[i];
+            const bool act = Dl > T(0) && jl < T(0);
+            d1 += act ? Dl*jl*sg*dx[i] : T(0); d2 += act ? Dl*dx[i]*dx[i] : T(0);
         }
         Spatial<T> S4, S5, D4, D5;
         link_spatial(W, xa, S4, S5);

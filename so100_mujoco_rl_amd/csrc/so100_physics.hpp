@@ -464,6 +464,7 @@ template <typename T> struct ArmRows {
     T a0[6];                                   // qacc_smooth of the arm
     T bf[6], Rf[6], bl[6], Rl[6], sg[6], fmax_[6];
     T cfv[6], clv[6];                          // the rows' constants without the a0 term: -aref = B Jv (+ K imp dist)
+    T Df[6], Dl[6];                            // 1/R of the friction rows (0 without friction loss) and of the ACTIVE limit rows (0 otherwise)
 };
 
 template <typename T>
@@ -530,6 +531,8 @@ SO100_HD void arm_row_consts(const T q[6], const T v[6], unsigned flags, ArmRows
         r.Rl[i] = (T(1) - imp)*trcp(imp) * T(so100g::DOF_INVWEIGHT0[i]);
         r.clv[i] = Bd*sg*v[i] + Kd*imp*dist;
         r.sg[i] = act ? sg : T(0);
+        r.Df[i] = (flags & F_FRICTIONLOSS) != 0u ? T(so100g::SOLIMP_D0/((1.0 - so100g::SOLIMP_D0)*so100g::DOF_INVWEIGHT0[i])) : T(0);
+        r.Dl[i] = act ? trcp(r.Rl[i]) : T(0);
     }
 }
 // friction-loss / limit row forces that go with a given acceleration (the block PGS's warm-start memory after a primal solve)

@@ -16,7 +16,8 @@ __global__ void __launch_bounds__(64) k_solve6(const float* in, float* out, unsi
     WorldFK<float> W; world_fk<float>(A.s, A.c, W);
     ContactsLds<float> cs{ cbuf, t }; cs.n = nc;
     Cube<float> ct{}; float Rc[9] = {1,0,0,0,1,0,0,0,1}, ap[3] = {0,0,0}, res = 0;
-    contact_solve_integrate<float>(q, v, qc, ctrl, ff, fl, aw, flags, iters, A, W, cs, false, ct, Rc, ap, dq, &res, nullptr);
+    int zones = in[t + 64*130] > 0.0f ? 5 : -1;
+    contact_solve_integrate<float>(q, v, qc, ctrl, ff, fl, aw, flags, iters, A, W, cs, false, ct, Rc, ap, dq, &res, &zones);
     for (int i = 0; i < 6; i++) { out[t + 64*i] = q[i]; out[t + 64*(6 + i)] = v[i]; out[t + 64*(12 + i)] = aw[i]; out[t + 64*(18 + i)] = ff[i] + fl[i] + dq[i]; }
     out[t + 64*24] = res;
 }
@@ -46,10 +47,11 @@ __global__ void __launch_bounds__(64) k_eval6(const float* in, float* out, int n
     WorldFK<float> W; world_fk<float>(s, c, W);
     ContactsLds<float> cs{ cbuf, t }; cs.n = nc;
     float Rc[9] = {1,0,0,0,1,0,0,0,1}, z3[3] = {0,0,0};
-    PrimalProblem<6, float, ContactsLds<float>> P{ W, cs, Marm, tau, r, Rc, z3, z3 };
+    int zones = 0;
+    PrimalProblem<6, float, ContactsLds<float>> P{ W, cs, Marm, tau, r, Rc, z3, z3, &zones };
     float g[6], H[21];
-    const float cost = P.eval<2>(x, g, H);
-    float acc = cost;
+    P.eval<2>(x, g, H);
+    float acc = 0.0f;
     for (int i = 0; i < 6; i++) acc += g[i];
     for (int i = 0; i < 21; i++) acc += H[i];
     out[t] = acc;
