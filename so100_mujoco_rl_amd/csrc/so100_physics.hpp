@@ -45,6 +45,14 @@ SO100_HD float trcp(float x) {
 #endif
 }
 SO100_HD double trcp(double x) { return 1.0/x; }
+// true if the predicate holds in any active lane of the wavefront (on the host: the one "lane" there is)
+SO100_HD bool wave_any(bool b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(b) != 0ull;
+#else
+    return b;
+#endif
+}
 SO100_HD float  tfloor(float x)  { return __builtin_floorf(x); }
 SO100_HD double tfloor(double x) { return __builtin_floor(x); }
 
@@ -558,11 +566,17 @@ SO100_HD void arm_pgs(T ff[6], T fl[6], int iters, const Arm<T>& A, const ArmRow
     // (armature-dominated M => nearly diagonal Minv) then converges in a few sweeps.
     T tq[6];                                              // joint-space constraint torque J^T f
     T rAf[6], rAl[6], rdet[6];                            // sweep-invariant reciprocals of the 2x2 blocks
+    // A joint whose limit row is inactive in EVERY lane of the wavefront (the usual case for most joints: 16 .. 64 envs per wave)
+    // takes the scalar friction update only -- a wave-uniform branch, the same arithmetic for the lanes (case 1 below).
+    bool lim[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         tq[i] = ff[i] + sg[i]*fl[i];
-        const T a = sym6(Minv, i, i), Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a;
-        rAf[i] = trcp(Af); rAl[i] = trcp(Al); rdet[i] = trcp(Af*Al - cx*cx);
+        lim[i] = wave_any(sg[i] != T(0));
+        const T a = sym6(Minv, i, i), Af = a + Rf[i];
+        rAf[i] = trcp(Af);
+        if (lim[i]) { const T Al = a + Rl[i], cx = sg[i]*a; rAl[i] = trcp(Al); rdet[i] = trcp(Af*Al - cx*cx); }
+        else { rAl[i] = T(0); rdet[i] = T(0); }
     }
     T change = T(0);                                      // largest |d acc_i| caused by the LAST sweep: the residual a caller can watch
     for (int it = 0; it < iters; it++) {
@@ -574,8 +588,16 @@ SO100_HD void arm_pgs(T ff[6], T fl[6], int iters, const Arm<T>& A, const ArmRow
             for (int j = 0; j < 6; j++) w += sym6(Minv, i, j)*tq[j];
             const T a = sym6(Minv, i, i);
             const T wo = w - a*tq[i];                     // contribution of the other joints
-            const T cf = bf[i] + wo, cl = bl[i] + sg[i]*wo;
-            const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a, F = fmax_[i];
+            const T cf = bf[i] + wo, F = fmax_[i];
+            if (!lim[i]) {                                // no lane has this joint at a limit: case (1) alone
+                const T fn = tclamp(-cf*rAf[i], -F, F);
+                ff[i] = fn; fl[i] = T(0);
+                change = tmax(change, tabs(fn - tq[i])*a);
+                tq[i] = fn;
+                continue;
+            }
+            const T cl = bl[i] + sg[i]*wo;
+            const T Af = a + Rf[i], Al = a + Rl[i], cx = sg[i]*a;
             // (1) limit row inactive
             const T f1 = tclamp(-cf*rAf[i], -F, F);
             const bool ok1 = (sg[i] == T(0)) || (cl + cx*f1 >= T(0));
