@@ -112,8 +112,8 @@ def cpu_baseline(kind, flags, iters, seconds=12.0):
 
 def sb3_vecenv_path(kind, flags, n, dev, steps=200):
     """The SB3-facing path (ref: main.py:57-63 hands the env to SB3, whose collect_rollouts calls VecEnv.step with numpy
-    actions): So100VecEnv.step = H2D actions + fused step kernel + D2H results as one hipGraph + the Python info
-    bookkeeping.  Same batch size and physics flags as the headline, policy not included (SB3 runs its own)."""
+    actions): So100VecEnv.step = ONE launch of the fused step kernel, which reads the actions from and writes its results to pinned host
+    memory itself, one stream sync, + the Python info bookkeeping.  Same batch size and physics flags as the headline, policy not included (SB3 runs its own)."""
     import numpy as np
     from so100_mujoco_rl_amd.vec_env import So100VecEnv
     env = So100VecEnv(kind, n, device=dev, flags=flags, seed=77, stagger_episodes=True)
@@ -127,7 +127,7 @@ def sb3_vecenv_path(kind, flags, n, dev, steps=200):
     dt = time.perf_counter() - t0
     env.close()
     return {"us_per_step": dt / steps * 1e6, "env_steps_per_s": n * steps / dt, "envs": n, "steps": steps,
-            "what": "So100VecEnv.step(numpy actions) -> numpy obs/rew/done/infos, one hipGraph per step, no policy"}
+            "what": "So100VecEnv.step(numpy actions) -> numpy obs/rew/done/infos: one kernel launch that reads / writes pinned host memory, one sync, no policy"}
 
 
 def source_sha16():

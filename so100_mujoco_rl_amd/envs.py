@@ -20,7 +20,7 @@ class So100Env:
     def __init__(self, env_kind=1, device=None, flags=F_REFERENCE, seed=0, render_mode=None, max_episode_steps=None, **kwargs):
         self.kind = env_kind
         self.observation_space, self.action_space = make_spaces(env_kind)
-        # a one-env So100VecEnv underneath: its numpy round trip (pinned staging, one hipGraph launch, one sync per step)
+        # a one-env So100VecEnv underneath: its numpy round trip (pinned host buffers the step kernel reads / writes directly, one launch, one sync per step)
         self._mk = lambda s: So100VecEnv(env_kind, 1, device=device, flags=flags, seed=s,
                                          max_episode_steps=K.MAX_EPISODE_STEPS[env_kind] if max_episode_steps is None else max_episode_steps)
         self._v = self._mk(seed)

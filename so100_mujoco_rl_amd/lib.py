@@ -115,6 +115,15 @@ def _check(rc, what):
         raise So100Error(f"{what} failed ({rc}): {load().so100_last_error().decode()}")
 
 
+def _hptr(t, dtype, shape):
+    """pointer of a PINNED host tensor (hipHostMalloc memory is mapped into the GPU's address space at the same address)"""
+    if t is None:
+        return None
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.device.type != "cpu" or not t.is_pinned():
+        raise So100Error(f"bad tensor: want {dtype} {tuple(shape)} contiguous in pinned host memory, got {t.dtype} {tuple(t.shape)} on {t.device}")
+    return t.data_ptr()
+
+
 def _ptr(t, dtype, shape, device):
     if t is None:
         return None
@@ -185,6 +194,16 @@ class So100Sim:
         io.inject_dev = _ptr(inject, torch.float32, (self.n, NINJECT), self.device)
         _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
         return self.obs, self.rew, self.done, self.trunc
+
+    def step_host(self, act, obs, rew, done, trunc, terminal_obs=None, ep_return=None, ep_length=None):
+        """The same env step with every boundary buffer in PINNED HOST memory: the kernel reads the actions and writes its results
+        over the host link itself -- one launch, no copy nodes (So100VecEnv's numpy path: 62 instead of 94 us per step at 4096 envs).
+        The results are valid after the stream is synchronised; the handle's device-side obs / rew / done tensors are NOT updated."""
+        io = StepIO(_hptr(act, torch.float32, (self.n, 6)), _hptr(obs, torch.float32, (self.n, self.obs_dim)), _hptr(rew, torch.float32, (self.n,)),
+                    _hptr(done, torch.uint8, (self.n,)), _hptr(trunc, torch.uint8, (self.n,)),
+                    _hptr(terminal_obs, torch.float32, (self.n, self.obs_dim)), _hptr(ep_return, torch.float32, (self.n,)),
+                    _hptr(ep_length, torch.int32, (self.n,)), None, None)
+        _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
 
     def set_policy(self, tensors):
         """tensors: dict name -> float32 device tensor (names: POLICY_TENSORS; SB3 keys: SB3_STATE_DICT_KEYS)."""

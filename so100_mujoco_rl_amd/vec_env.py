@@ -81,7 +81,7 @@ class So100VecEnv(_VecEnvBase):
         self._stagger = stagger_episodes
         self._actions = torch.zeros(num_envs, 6, dtype=torch.float32, device=self.device)
         self._infos = [{} for _ in range(num_envs)]
-        # pinned host staging: one batch of async D2H copies + ONE stream sync per step_wait
+        # pinned host buffers: the step kernel reads the actions from and writes its results to them directly (see _round_trip)
         od = self.sim.obs_dim
         self._h_obs = torch.empty(num_envs, od, dtype=torch.float32, pin_memory=True)
         self._h_rew = torch.empty(num_envs, dtype=torch.float32, pin_memory=True)
@@ -91,9 +91,10 @@ class So100VecEnv(_VecEnvBase):
         self._h_tobs = torch.empty(num_envs, od, dtype=torch.float32, pin_memory=True)
         self._h_epr = torch.empty(num_envs, dtype=torch.float32, pin_memory=True)
         self._h_epl = torch.empty(num_envs, dtype=torch.int32, pin_memory=True)
-        # the whole host round trip of one step -- actions H2D, the fused step kernel, results D2H -- is one hipGraph launch
-        # (captured on the second step; so100_step allocates nothing and never synchronises, include/so100_sim.h)
-        self._use_graph = use_graph; self._graph = None; self._eager_steps = 0
+        # use_graph (the historical name of the switch) = True: zero-copy round trip -- ONE kernel launch per step, the kernel itself
+        # moves actions / results over the host link (62 us per step at 4096 envs).  False: the staged path -- actions H2D, the step
+        # kernel on device buffers, seven D2H copies (94 us even when replayed from one hipGraph); kept as the cross-check.
+        self._zero_copy = bool(use_graph)
         self._dirty = []                                # infos filled on the previous step (cleared lazily)
         self._t0 = time.time()
         self.spec = type("Spec", (), {"id": K.ENV_IDS[self.kind], "max_episode_steps": self.sim.cfg.max_episode_steps,
@@ -120,6 +121,9 @@ class So100VecEnv(_VecEnvBase):
         self._h_act.numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 6)
 
     def _round_trip(self):
+        if self._zero_copy:
+            self.sim.step_host(self._h_act, self._h_obs, self._h_rew, self._h_done, self._h_trunc, self._h_tobs, self._h_epr, self._h_epl)
+            return
         self._actions.copy_(self._h_act, non_blocking=True)
         obs, rew, done, trunc = self.sim.step(self._actions)
         self._h_obs.copy_(obs, non_blocking=True); self._h_rew.copy_(rew, non_blocking=True)
@@ -128,17 +132,7 @@ class So100VecEnv(_VecEnvBase):
         self._h_epr.copy_(self.sim.ep_return, non_blocking=True); self._h_epl.copy_(self.sim.ep_length, non_blocking=True)
 
     def step_wait(self):
-        if self._graph is not None:
-            self._graph.replay()
-        elif self._use_graph and self._eager_steps >= 1:
-            torch.cuda.current_stream(self.device).synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._round_trip()
-            self._graph = g
-            g.replay()                                   # capture records, it does not run
-        else:
-            self._round_trip(); self._eager_steps += 1
+        self._round_trip()
         torch.cuda.current_stream(self.device).synchronize()
         # fresh arrays every step: SB3 keeps `_last_obs` alive across the next env.step()
         obs_h = self._h_obs.numpy().copy(); rew_h = self._h_rew.numpy().copy()
