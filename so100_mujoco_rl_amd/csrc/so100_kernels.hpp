@@ -60,10 +60,14 @@ struct StepPtrs {
 // FL >= 0: the physics flags are a compile-time constant (dead constraint families are not even compiled in:
 // fewer live registers, smaller loop body); FL < 0: flags read from the handle at run time.
 // The constraint-free variant fits 256 registers: asking for 2 waves per SIMD keeps the latency hiding that large
-// batches need (1 M envs: 2 waves/SIMD 2.3 G env-steps/s, 1 wave/SIMD 1.5 G); the constrained variants and the
-// look-at envs (more task state) need > 256 and would spill.
-template <int KIND, int FL>
-__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_kind<KIND>()) ? SO100_FREE_WAVES : 1)) so100_step_fused(SimParams p, StepPtrs io) {
+// batches need (1 M envs: 2 waves/SIMD 2.1 G env-steps/s, 1 wave/SIMD 1.5 G); the constrained variants and the
+// look-at envs (more task state) need > 256.  DENSE = the same kernel held to 256 registers (2 waves per SIMD) with the rest
+// in scratch: for the friction / limit / cube-floor variants (flags 7, 11) that is faster once the batch fills the chip twice
+// (measured, 262 144 envs: 0.57 -> 0.74 G env-steps/s; at 65 536 envs 0.54 -> 0.42, so KindOps::step picks by batch size;
+// the pad-contact variants lose with it: 1.4 KB of scratch per lane already).
+constexpr int DENSE_MIN_ENVS = 131072;
+template <int KIND, int FL, bool DENSE = false>
+__global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_kind<KIND>()) ? SO100_FREE_WAVES : DENSE ? 2 : 1)) so100_step_fused(SimParams p, StepPtrs io) {
     const int env = blockIdx.x*WG + threadIdx.x;
     if (env >= p.n) return;
     if (FL >= 0) p.flags = (unsigned)FL;
@@ -231,14 +235,17 @@ template <int KIND> hipError_t KindOps<KIND>::step(const SimParams& prm, const S
     const dim3 g = mw ? dim3((unsigned)((prm.n + prm.epw - 1)/prm.epw)) : grid_for(prm.n), b(mw ? 256 : WG);
 #define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, prm, io); \
                              else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, prm, io); } while (0)
+#define SO100_STEP_ROWS(FLV) do { if (prm.n >= DENSE_MIN_ENVS) hipLaunchKernelGGL((so100_step_fused<KIND, FLV, true>), g, b, 0, st, prm, io); \
+                                  else SO100_STEP(FLV); } while (0)
     switch (prm.flags) {
     case SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_CUBE_PINNED); break;
-    case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED); break;
-    case SO100_F_NOPADS: SO100_STEP(SO100_F_NOPADS); break;
+    case SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED: SO100_STEP_ROWS(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_CUBE_PINNED); break;
+    case SO100_F_NOPADS: SO100_STEP_ROWS(SO100_F_NOPADS); break;
     case SO100_F_REFERENCE: SO100_STEP(SO100_F_REFERENCE); break;
     case SO100_F_CONTACT5: if constexpr (reach_kind<KIND>()) { SO100_STEP(SO100_F_CONTACT5); } else { SO100_STEP(-1); } break;
     default: SO100_STEP(-1); break;
     }
+#undef SO100_STEP_ROWS
 #undef SO100_STEP
     return hipGetLastError();
 }

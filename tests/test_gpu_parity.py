@@ -662,6 +662,40 @@ def test_multiwave_step_kernel_equals_throughput_kernel(kind, flags):
     torch.testing.assert_close(q1, q2[:, :n], rtol=0, atol=2e-6); torch.testing.assert_close(v1, v2[:, :n], rtol=0, atol=2e-5)
 
 
+def test_dense_throughput_kernel_131072():
+    """N >= 131 072 with friction / limit / cube-floor physics: so100_step takes the 2-waves-per-SIMD build of the throughput kernel
+    (256 registers + scratch).  Same source, so the results must be BIT-IDENTICAL to the 1-wave-per-SIMD build that two half-size
+    handles take (65 536 envs each, env_id_offset keeps the Philox streams), and 32 sampled envs are held to the fp64 oracle."""
+    n, steps = 131072, 5
+    rs = np.random.RandomState(12)
+    sample = np.sort(rs.choice(n, 32, replace=False)); sample[0] = 0; sample[-1] = n - 1
+    sim = _sim(1, n, flags=REF, solver_iters=4, seed=23, max_episode_steps=3)
+    orc = [O.OracleEnv(1, flags=REF, iters=0, seed=23, env_id=int(i)) for i in sample]
+    for e in orc:
+        e.e.max_episode_steps = 3
+    sim.reset(); [e.reset() for e in orc]
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    acts = [torch.rand(n, 6, device="cuda", generator=g) * 2 - 1 for _ in range(steps)]
+    trace = []
+    for t in range(steps):
+        ob, r, d, tr = sim.step(acts[t])
+        trace.append(torch.cat([ob, r[:, None], d[:, None].float()], 1).clone())
+        a_h = acts[t][sample].cpu().numpy()
+        res = [e.step(a_h[j], autoreset=True) for j, e in enumerate(orc)]
+        np.testing.assert_allclose(ob[sample].cpu().numpy(), np.stack([x[0] for x in res]), rtol=0, atol=2e-5)
+        np.testing.assert_allclose(r[sample].cpu().numpy(), np.array([x[1] for x in res]), rtol=0, atol=1e-4)
+        np.testing.assert_array_equal(d[sample].cpu().numpy().astype(bool), np.array([x[2] or x[3] for x in res]))
+    full = torch.cat(trace, 1); sim.close()
+    halves = []
+    for off in (0, n // 2):
+        s2 = _sim(1, n // 2, flags=REF, solver_iters=4, seed=23, max_episode_steps=3, env_id_offset=off); s2.reset(); tr2 = []
+        for t in range(steps):
+            ob, r, d, _ = s2.step(acts[t][off:off + n // 2].contiguous())
+            tr2.append(torch.cat([ob, r[:, None], d[:, None].float()], 1).clone())
+        halves.append(torch.cat(tr2, 1)); s2.close()
+    assert torch.equal(torch.cat(halves, 0), full)
+
+
 def test_large_batch_dispatch_65536_vs_oracle():
     """N = 65 536: so100_step takes the production throughput kernel (so100_step_fused, one wave per 64 envs, the
     __launch_bounds__(64, 2) variant for the contact-free flags) and so100_policy_forward walks 1024 tiles with a 512-block
