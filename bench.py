@@ -248,7 +248,7 @@ def main():
         ones = torch.ones(1, device=dev); dist.all_reduce(ones); rccl_ranks = int(ones.item())
         assert rccl_ranks == world, (rccl_ranks, world)
     n = args.envs
-    sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=2, contact_iters=6, seed=1234 + rank, env_id_offset=rank * n)
+    sim = So100Sim(kind, n, device=dev, flags=flags, solver_iters=2, contact_iters=20, seed=1234 + rank, env_id_offset=rank * n)
     obs = sim.reset()
     # stagger the episodes so TimeLimit resets are spread over the rollout
     g = torch.Generator(device=dev); g.manual_seed(1234 + rank)

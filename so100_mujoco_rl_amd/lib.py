@@ -135,7 +135,7 @@ def _ptr(t, dtype, shape, device):
 class So100Sim:
     """One batched simulator handle on one GPU (one per process per device)."""
 
-    def __init__(self, env_kind, num_envs, device=None, flags=F_REFERENCE, solver_iters=2, contact_iters=6,
+    def __init__(self, env_kind, num_envs, device=None, flags=F_REFERENCE, solver_iters=2, contact_iters=20,
                  frame_skip=16, max_episode_steps=None, seed=0, env_id_offset=0):
         self.L = load()
         if not torch.cuda.is_available():

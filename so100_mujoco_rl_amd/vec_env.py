@@ -69,7 +69,7 @@ class So100VecEnv(_VecEnvBase):
     metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
 
     def __init__(self, env_id="Env01-v1", num_envs=4096, device=None, flags=F_REFERENCE, seed=0, env_id_offset=0,
-                 solver_iters=2, contact_iters=6, max_episode_steps=None, stagger_episodes=False, full_infos=False, use_graph=True):
+                 solver_iters=2, contact_iters=20, max_episode_steps=None, stagger_episodes=False, full_infos=False, use_graph=True):
         self.env_id = env_id
         self.kind = kind_from_id(env_id) if isinstance(env_id, str) else int(env_id)
         obs_space, act_space = make_spaces(self.kind)
