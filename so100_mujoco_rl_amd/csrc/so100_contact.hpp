@@ -49,7 +49,41 @@ enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY,
 // detection (4-bit hash: distinct for the same corner of different pads; a collision only costs a worse first guess).
 SO100_HD int contact_id_hash(int id) { return (id ^ (id >> 4)) & 15; }
 
+// Cooperative lanes.  When a wavefront holds fewer envs than lanes (the multi-wave kernels spread small batches over all CUs: 16 or
+// 32 envs per 64-lane wave), the contact wave gives each env a group of `nparts` = 4 or 2 ADJACENT lanes (a quad, or half of one):
+// every lane of the group holds the same env (same inputs, same x, g, H: all replicated arithmetic is bit-identical), the loops over
+// pads / contact records are dealt out over the group (record s belongs to lane s mod nparts), and the partial sums meet in
+// quad-permute DPP additions.  Stores with COOP = false (private arrays: the one-wave kernel, the host) are a group of one.
+#if defined(__HIP_DEVICE_COMPILE__)
+SO100_HD float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }   // lanes 0<->1, 2<->3
+SO100_HD float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }   // lanes 0<->2, 1<->3
+SO100_HD int quad_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }
+SO100_HD int quad_xor2(int v) { return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true); }
+#else
+template <typename T> SO100_HD T quad_xor1(T v) { return v; }
+template <typename T> SO100_HD T quad_xor2(T v) { return v; }
+#endif
+template <class Store, typename T> SO100_HD T coop_sum(const Store& cs, T v) {
+    if constexpr (Store::COOP) { if (cs.nparts >= 2) v += quad_xor1(v); if (cs.nparts == 4) v += quad_xor2(v); }
+    return v;
+}
+// the value held by the group's first lane
+template <class Store> SO100_HD int coop_first(const Store& cs, int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (Store::COOP) {
+        if (cs.nparts == 4) v = __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true);        // quad_perm [0,0,0,0]
+        else if (cs.nparts == 2) v = __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true);   // quad_perm [0,0,2,2]
+    }
+#endif
+    return v;
+}
+template <class Store> SO100_HD int coop_or(const Store& cs, int v) {
+    if constexpr (Store::COOP) { if (cs.nparts >= 2) v |= quad_xor1(v); if (cs.nparts == 4) v |= quad_xor2(v); }
+    return v;
+}
+
 template <typename T> struct ContactsPriv {                 // one env's records in a private array
+    static constexpr bool COOP = false; static constexpr int part = 0, nparts = 1;
     T a[MAXC*CF]; int n = 0, dropped = 0;
     unsigned char pcode[MAXC]; int prev_n = 0;
     SO100_HD T get(int s, int f) const { return a[s*CF + f]; }
@@ -58,7 +92,9 @@ template <typename T> struct ContactsPriv {                 // one env's records
     SO100_HD void setp(int k, int v) { pcode[k] = (unsigned char)v; }
 };
 template <typename T> struct ContactsLds {                  // [record][field][lane] image shared by the waves of a workgroup
-    T* base; int lane; unsigned char* pbase; int n = 0, dropped = 0, prev_n = 0;       // pbase: [MAXC][64] bytes OUTSIDE any aliased region
+    static constexpr bool COOP = true;
+    T* base; int lane; unsigned char* pbase; int part = 0, nparts = 1;                 // lane: the ENV's column; part of nparts: this lane's share of it
+    int n = 0, dropped = 0, prev_n = 0;                                               // pbase: [MAXC][64] bytes OUTSIDE any aliased region
     SO100_HD T get(int s, int f) const { return base[(s*CF + f)*64 + lane]; }
     SO100_HD void set(int s, int f, T v) { base[(s*CF + f)*64 + lane] = v; }
     SO100_HD int getp(int k) const { return pbase[k*64 + lane]; }
@@ -136,10 +172,17 @@ template <typename T> SO100_HD void contact_frame(const T n[3], T t1[3], T t2[3]
 
 // append one contact (returns false when the pad budget is exhausted).  vrel = relative point velocity geom2 - geom1.
 template <typename T, class Store>
+SO100_HD void contact_put(Store& cs, int s, int kind, int id, const T p[3], const T n[3], T dist, const T vrel[3]);
+template <typename T, class Store>
 SO100_HD bool contact_add(Store& cs, int kind, int id, const T p[3], const T n[3], T dist, const T vrel[3]) {
     if (kind != 0 && cs.n >= MAXPADC) { cs.dropped++; return false; }
     if (cs.n >= MAXC) { cs.dropped++; return false; }
-    const int s = cs.n++;
+    contact_put(cs, cs.n++, kind, id, p, n, dist, vrel);
+    return true;
+}
+// write record s (no budget logic: the caller owns the slot)
+template <typename T, class Store>
+SO100_HD void contact_put(Store& cs, int s, int kind, int id, const T p[3], const T n[3], T dist, const T vrel[3]) {
     int mask0 = 15;                                            // a new contact: expect all four edges to push (an impact sticks first)
 #pragma unroll 1
     for (int k = 0; k < cs.prev_n; k++) { const int c = cs.getp(k); if ((c >> 4) == contact_id_hash(id)) mask0 = c & 15; }
@@ -156,7 +199,6 @@ SO100_HD bool contact_add(Store& cs, int kind, int id, const T p[3], const T n[3
     cs.set(s, C_NX, n[0]); cs.set(s, C_NY, n[1]); cs.set(s, C_NZ, n[2]);
     cs.set(s, C_KD, K*imp*dist); cs.set(s, C_RINV, trcp(R)); cs.set(s, C_KIND, T(kind | (id << 3) | (mask0 << 11)));
     cs.set(s, C_VX, B*vrel[0]); cs.set(s, C_VY, B*vrel[1]); cs.set(s, C_VZ, B*vrel[2]);
-    return true;
 }
 
 // the cube's point velocity / acceleration: x = (linear, world frame; angular, BODY frame) like MuJoCo's free-joint dofs
@@ -379,23 +421,68 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
     }
     const bool near_floor = (flags & F_PADS_FLOOR) != 0u && zmin < T(PAD_REACH);
     const bool near_cube = dc2 < T((PAD_REACH + so100g::CUBE_HALF*1.7320508075688772)*(PAD_REACH + so100g::CUBE_HALF*1.7320508075688772));
+    auto pad_frame = [&](int g, T R[9], T o[3], T h[3], T c[3]) {
+        const bool l5 = so100g::PAD_LINK[g] == 5;
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = l5 ? W.R5[k] : W.R4[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) o[k] = l5 ? W.o[5][k] : W.o[4][k];
+        const T pp[3] = { T(so100g::PAD_POS[g][0]), T(so100g::PAD_POS[g][1]), T(so100g::PAD_POS[g][2]) };
+        h[0] = T(so100g::PAD_SIZE[g][0]); h[1] = T(so100g::PAD_SIZE[g][1]); h[2] = T(so100g::PAD_SIZE[g][2]);
+        c[0] = o[0] + R[0]*pp[0] + R[1]*pp[1] + R[2]*pp[2]; c[1] = o[1] + R[3]*pp[0] + R[4]*pp[1] + R[5]*pp[2]; c[2] = o[2] + R[6]*pp[0] + R[7]*pp[1] + R[8]*pp[2];
+        return l5;
+    };
+    bool coop_floor_done = false;
+    if constexpr (Store::COOP) {
+        if (cs.nparts > 1) {
+            // Pad/floor pass dealt out over the env's lanes (pad g belongs to lane g mod nparts): first every lane COUNTS the contacts
+            // of its pads, the counts meet (3 bits per pad), then every lane writes its records at the slots the serial order gives
+            // them -- pad by pad, corner by corner, the first MAXPADC kept.  Same list as the serial pass, 4 (2) times faster.
+            coop_floor_done = true;
+            if (near_floor) {
+                int counts = 0;
+#pragma unroll 1
+                for (int g = cs.part; g < so100g::NPAD; g += cs.nparts) {
+                    T R[9], o[3], h[3], c[3];
+                    pad_frame(g, R, o, h, c);
+                    int cnt = 0;
+                    if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) plane_box<T>(c, R, h, [&](const T*, T, int) { cnt++; });
+                    counts |= cnt << (3*g);
+                }
+                counts = coop_or(cs, counts);
+                int total = 0;
+#pragma unroll
+                for (int g = 0; g < so100g::NPAD; g++) total += (counts >> (3*g)) & 7;
+#pragma unroll 1
+                for (int g = cs.part; g < so100g::NPAD; g += cs.nparts) {
+                    if (((counts >> (3*g)) & 7) == 0) continue;
+                    int off = 0;
+                    for (int hh = 0; hh < g; hh++) off += (counts >> (3*hh)) & 7;
+                    T R[9], o[3], h[3], c[3];
+                    const bool l5 = pad_frame(g, R, o, h, c);
+                    int idx = 0;
+                    plane_box<T>(c, R, h, [&](const T* p, T dist, int corner) {
+                        const int slot = off + idx++;
+                        if (slot < MAXPADC) { T vr[3]; point_motion(pick_spatial(l5, V4, V5), p, vr); contact_put(cs, slot, l5 ? 2 : 1, 8*g + corner, p, nz, dist, vr); }
+                    });
+                }
+                cs.n = total < MAXPADC ? total : MAXPADC; cs.dropped = total - cs.n;
+            }
+        }
+    }
+    const bool serial_lane = !Store::COOP || cs.part == 0;   // the pad/cube pass and the cube's own floor contacts run on the group's first lane
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {                   // pass 0: pad/floor, pass 1: pad/cube
+        if (pass == 0 && coop_floor_done) continue;
+        if (pass == 1 && !serial_lane) continue;
         if (pass == 0 && !near_floor) continue;
         if (pass == 1 && !near_cube) continue;
         if (pass == 0 && (flags & F_PADS_FLOOR) == 0u) continue;
         if (pass == 1 && ((flags & F_PADS_CUBE) == 0u || !cube_live)) continue;
 #pragma unroll 1
         for (int g = 0; g < so100g::NPAD; g++) {
-            const bool l5 = so100g::PAD_LINK[g] == 5;
-            T R[9], o[3];
-#pragma unroll
-            for (int k = 0; k < 9; k++) R[k] = l5 ? W.R5[k] : W.R4[k];
-#pragma unroll
-            for (int k = 0; k < 3; k++) o[k] = l5 ? W.o[5][k] : W.o[4][k];
-            const T pp[3] = { T(so100g::PAD_POS[g][0]), T(so100g::PAD_POS[g][1]), T(so100g::PAD_POS[g][2]) };
-            const T h[3] = { T(so100g::PAD_SIZE[g][0]), T(so100g::PAD_SIZE[g][1]), T(so100g::PAD_SIZE[g][2]) };
-            const T c[3] = { o[0] + R[0]*pp[0] + R[1]*pp[1] + R[2]*pp[2], o[1] + R[3]*pp[0] + R[4]*pp[1] + R[5]*pp[2], o[2] + R[6]*pp[0] + R[7]*pp[1] + R[8]*pp[2] };
+            T R[9], o[3], h[3], c[3];
+            const bool l5 = pad_frame(g, R, o, h, c);
             if (pass == 0) {
                 if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) {
                     plane_box<T>(c, R, h, [&](const T* p, T dist, int corner) {
@@ -422,11 +509,16 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             }
         }
     }
-    if (coupled && (flags & F_FLOOR) != 0u) {
+    if (coupled && serial_lane && (flags & F_FLOOR) != 0u) {
         plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist, int corner) {
             T vr[3]; cube_point_motion(Rc, cube.pos, cube.vel, p, vr);
             contact_add(cs, 0, 128 + corner, p, nz, dist, vr);
         });
+    }
+    if constexpr (Store::COOP) {
+        if (cs.nparts > 1 && (flags & F_PADS_CUBE) != 0u) {   // what the first lane appended is the group's
+            cs.n = coop_first(cs, cs.n); cs.dropped = coop_first(cs, cs.dropped); coupled = coop_first(cs, coupled ? 1 : 0) != 0;
+        }
     }
     if (cs.n > 0) cs.prev_n = cs.n;                            // (the solve fills the list: every row pass leaves id | final mask per record)
     return coupled;
@@ -498,52 +590,18 @@ template <int ND, typename T, class Store> struct PrimalProblem {
     template <int MODE, bool FORCED = false> SO100_HD void eval(const T x[ND], T g[ND], T H[NH], bool* same = nullptr) const {
         const int zin = *zones;
         int zout = 0, differ = 0;
+        // ---- contacts first, into zero-initialised accumulators (this lane's share of the records; the shares meet below)
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < NH; i++) H[i] = T(0);
-#pragma unroll
-            for (int i = 0; i < 21; i++) H[i] = Marm[i];
         }
-        // smooth part, arm: 1/2 x'Mx - x'tau
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            T t = T(0);
-#pragma unroll
-            for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
-            g[i] = t - tau[i];
-        }
-        if (ND == 12) {
-            const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
-#pragma unroll
-            for (int i = 0; i < 3; i++) {
-                const T dl = x[6 + i] - a0c[i], da = x[9 + i];
-                g[6 + i] = m*dl; g[9 + i] = I*da;
-                if (MODE == 2) { H[SO100_TRI(6 + i, 6 + i)] = m; H[SO100_TRI(9 + i, 9 + i)] = I; }
-            }
-        }
-        // friction-loss rows (Huber) and limit rows (one-sided) of the arm: J = +-e_i.  Branch-free: the Huber gradient is the
-        // clamped quadratic's, absent rows have D = 0 (rows.Df / rows.Dl) -- 20 instructions per joint instead of 80 behind branches.
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const T F = rows.fmax_[i], D = rows.Df[i], fq = D*(x[i] + rows.cfv[i]);      // the quadratic zone's force
-            const int zone = FORCED ? ((zin >> (3*i)) & 3) : (F > T(0) ? (fq <= -F ? 1 : fq >= F ? 2 : 0) : 0);
-            const T fr = zone == 1 ? -F : zone == 2 ? F : fq;
-            if (MODE >= 1) g[i] += fr;
-            if (MODE == 2) H[SO100_TRI(i, i)] += zone == 0 ? D : T(0);
-            zout |= zone << (3*i);
-            const T sg = rows.sg[i], Dl = rows.Dl[i], jl = sg*x[i] + rows.clv[i];
-            const bool act = FORCED ? ((zin >> (3*i + 2)) & 1) != 0 : (Dl > T(0) && jl < T(0));
-            if (MODE >= 1) g[i] += act ? sg*Dl*jl : T(0);
-            if (MODE == 2) H[SO100_TRI(i, i)] += act ? Dl : T(0);
-            zout |= act ? 4 << (3*i) : 0;
-        }
-        if (MODE == 2 && !FORCED) { differ = zout ^ zin; *zones = zout; }
+        T gc[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };           // the contacts' gradient on the cube's dofs (ND = 12)
         // contacts
         Spatial<T> S4, S5;
         link_spatial(W, x, S4, S5);
         T F45[3] = { T(0), T(0), T(0) }, T45[3] = { T(0), T(0), T(0) }, F5[3] = { T(0), T(0), T(0) }, T5[3] = { T(0), T(0), T(0) };   // wrenches on links 4 + 5, on link 5
 #pragma unroll 1
-        for (int s = 0; s < cs.n; s++) {
+        for (int s = cs.part; s < cs.n; s += cs.nparts) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
             const int code = (int)cs.get(s, C_KIND), kind = code & 7;
@@ -583,10 +641,10 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 if (ND == 12 && cube_side) {
                     const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
                     T tw[3]; cross(r, Fv, tw);
-                    g[6] += Fv[0]; g[7] += Fv[1]; g[8] += Fv[2];
-                    g[9]  += Rc[0]*tw[0] + Rc[3]*tw[1] + Rc[6]*tw[2];
-                    g[10] += Rc[1]*tw[0] + Rc[4]*tw[1] + Rc[7]*tw[2];
-                    g[11] += Rc[2]*tw[0] + Rc[5]*tw[1] + Rc[8]*tw[2];
+                    gc[0] += Fv[0]; gc[1] += Fv[1]; gc[2] += Fv[2];
+                    gc[3] += Rc[0]*tw[0] + Rc[3]*tw[1] + Rc[6]*tw[2];
+                    gc[4] += Rc[1]*tw[0] + Rc[4]*tw[1] + Rc[7]*tw[2];
+                    gc[5] += Rc[2]*tw[0] + Rc[5]*tw[1] + Rc[8]*tw[2];
                 }
             }
             if (MODE == 2) {
@@ -624,15 +682,62 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 }
             }
         }
-        if (MODE >= 1) {
-            // contact wrenches -> joint space: g_i += z_i . (T - o_i x F), links >= i
+        // ---- the shares of the group's lanes meet (a group of one: nothing happens)
+        if constexpr (Store::COOP) {
+            if (cs.nparts > 1) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;
-                T oxf[3]; cross(W.o[i], Fa, oxf);
-                g[i] += W.z[i][0]*(Ta[0] - oxf[0]) + W.z[i][1]*(Ta[1] - oxf[1]) + W.z[i][2]*(Ta[2] - oxf[2]);
+                for (int k = 0; k < 3; k++) { F45[k] = coop_sum(cs, F45[k]); T45[k] = coop_sum(cs, T45[k]); F5[k] = coop_sum(cs, F5[k]); T5[k] = coop_sum(cs, T5[k]); }
+                if (ND == 12) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) gc[k] = coop_sum(cs, gc[k]);
+                }
+                if (MODE == 2) {
+#pragma unroll
+                    for (int i = 0; i < NH; i++) H[i] = coop_sum(cs, H[i]);
+                }
+                differ = coop_or(cs, differ);
             }
         }
+        // ---- smooth part, arm: 1/2 x'Mx - x'tau (+ the cube's), then the contact wrenches -> joint space: g_i += z_i . (T - o_i x F), links >= i
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            T t = T(0);
+#pragma unroll
+            for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
+            const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;
+            T oxf[3]; cross(W.o[i], Fa, oxf);
+            g[i] = (t - tau[i]) + (W.z[i][0]*(Ta[0] - oxf[0]) + W.z[i][1]*(Ta[1] - oxf[1]) + W.z[i][2]*(Ta[2] - oxf[2]));
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int i = 0; i < 21; i++) H[i] += Marm[i];
+        }
+        if (ND == 12) {
+            const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const T dl = x[6 + i] - a0c[i], da = x[9 + i];
+                g[6 + i] = m*dl + gc[i]; g[9 + i] = I*da + gc[3 + i];
+                if (MODE == 2) { H[SO100_TRI(6 + i, 6 + i)] += m; H[SO100_TRI(9 + i, 9 + i)] += I; }
+            }
+        }
+        // friction-loss rows (Huber) and limit rows (one-sided) of the arm: J = +-e_i.  Branch-free: the Huber gradient is the
+        // clamped quadratic's, absent rows have D = 0 (rows.Df / rows.Dl) -- 20 instructions per joint instead of 80 behind branches.
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const T F = rows.fmax_[i], D = rows.Df[i], fq = D*(x[i] + rows.cfv[i]);      // the quadratic zone's force
+            const int zone = FORCED ? ((zin >> (3*i)) & 3) : (F > T(0) ? (fq <= -F ? 1 : fq >= F ? 2 : 0) : 0);
+            const T fr = zone == 1 ? -F : zone == 2 ? F : fq;
+            if (MODE >= 1) g[i] += fr;
+            if (MODE == 2) H[SO100_TRI(i, i)] += zone == 0 ? D : T(0);
+            zout |= zone << (3*i);
+            const T sg = rows.sg[i], Dl = rows.Dl[i], jl = sg*x[i] + rows.clv[i];
+            const bool act = FORCED ? ((zin >> (3*i + 2)) & 1) != 0 : (Dl > T(0) && jl < T(0));
+            if (MODE >= 1) g[i] += act ? sg*Dl*jl : T(0);
+            if (MODE == 2) H[SO100_TRI(i, i)] += act ? Dl : T(0);
+            zout |= act ? 4 << (3*i) : 0;
+        }
+        if (MODE == 2 && !FORCED) { differ |= zout ^ zin; *zones = zout; }
         if (MODE == 2 && !FORCED && same) *same = differ == 0;
     }
 
@@ -670,8 +775,9 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         Spatial<T> S4, S5, D4, D5;
         link_spatial(W, xa, S4, S5);
         link_spatial(W, dx, D4, D5);
+        T c1_ = T(0), c2_ = T(0);                                 // the contacts' share of this lane
 #pragma unroll 1
-        for (int s = 0; s < cs.n; s++) {
+        for (int s = cs.part; s < cs.n; s += cs.nparts) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
             const int kind = (int)cs.get(s, C_KIND) & 7;
@@ -694,8 +800,9 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             const T dn = ND == 6 ? wd[2] : dot(n, wd), e1 = ND == 6 ? wd[1] : dot(t1, wd), e2 = ND == 6 ? -wd[0] : dot(t2, wd);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 }, jd[4] = { dn + e1, dn - e1, dn + e2, dn - e2 };
 #pragma unroll
-            for (int e = 0; e < 4; e++) if (jar[e] < T(0)) { d1 += D*jar[e]*jd[e]; d2 += D*jd[e]*jd[e]; }
+            for (int e = 0; e < 4; e++) if (jar[e] < T(0)) { c1_ += D*jar[e]*jd[e]; c2_ += D*jd[e]*jd[e]; }
         }
+        d1 += coop_sum(cs, c1_); d2 += coop_sum(cs, c2_);
     }
 };
 

@@ -111,6 +111,10 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
     float aw3[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };       // contact wave: arm acceleration of its last solve (Newton warm start)
+    // Contact wave: with p.epw < 64 envs per workgroup each env gets 64 / p.epw adjacent lanes (so100_contact.hpp: cooperative lanes);
+    // el = the env's column in the LDS images, part = this lane's place in the env's group.
+    const int np3 = 64/p.epw, sh3 = np3 == 4 ? 2 : np3 == 2 ? 1 : 0;
+    const int el = lane >> sh3, part3 = lane & (np3 - 1);
     if (wave == 0) {
         e.res = 0.0f; e.cstat = 0;
         if (pads) {
@@ -144,7 +148,8 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     }
     if (pads && wave == 3) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) aw3[i] = xk[6 + i][lane];
+        for (int i = 0; i < 6; i++) aw3[i] = xk[6 + i][el];
+        xa[12][lane] = 0.0f;                               // (columns >= p.epw are never written again: no contacts there)
     }
     // (Tried: letting wave 2 run the cube's 16 substeps back to back ahead of the arm when no pad can touch it.  A workgroup
     // barrier needs every wave, so the others simply waited for it at the first one: 72 -> 101 us per step.  The cube stays in
@@ -175,7 +180,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         SO100_PROF(3);                                     // barrier 1 wait
         after_first_barrier(sub);
         // ---- first half of the substep: everything that does not need the other waves' results
-        WorldFK<float> W3; Arm<float> A3; ContactsLds<float> cs3{ L.cbuf, lane, L.pbuf };     // contact wave only
+        WorldFK<float> W3; Arm<float> A3; ContactsLds<float> cs3{ L.cbuf, el, L.pbuf, part3, np3 };     // contact wave only
         cs3.prev_n = memo.prev_n;
         float Rc3[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f }, cpos3[3] = { 0.0f, 0.0f, 0.0f };
         bool coupled3 = false, any3 = false;
@@ -202,7 +207,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         } else if (wave == 3 && pads) {
             float v3[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][lane]; A3.c[i] = xq[6 + i][lane]; v3[i] = xq[12 + i][lane]; }
+            for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][el]; A3.c[i] = xq[6 + i][el]; v3[i] = xq[12 + i][el]; }
             world_fk<float>(A3.s, A3.c, W3);
             Cube<float> c3b;
 #pragma unroll
@@ -211,15 +216,15 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             for (int i = 0; i < 6; i++) c3b.vel[i] = 0.0f;
             if (padcube) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) { c3b.pos[i] = xc[i][lane]; cpos3[i] = c3b.pos[i]; }
-                float qn[4] = { xc[3][lane], xc[4][lane], xc[5][lane], xc[6][lane] };
+                for (int i = 0; i < 3; i++) { c3b.pos[i] = xc[i][el]; cpos3[i] = c3b.pos[i]; }
+                float qn[4] = { xc[3][el], xc[4][el], xc[5][el], xc[6][el] };
 #pragma unroll
-                for (int i = 0; i < 6; i++) c3b.vel[i] = xc[7 + i][lane];
+                for (int i = 0; i < 6; i++) c3b.vel[i] = xc[7 + i][el];
                 quat_normalize(qn); quat_to_mat(qn, Rc3);
             }
             coupled3 = detect_pad_contacts<float>(W3, v3, c3b, Rc3, p.flags, padcube, cs3);
             memo.prev_n = cs3.prev_n;
-            xa[12][lane] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
+            if (part3 == 0) xa[12][el] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
             any3 = __any(cs3.n > 0);
             SO100_PROF(4);                                 // FK + narrowphase (wave 3)
         }
@@ -250,22 +255,26 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             if (cs3.n > 0) {
                 float q3[6], v3[6], c3[6], tau3[6], x3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
 #pragma unroll
-                for (int i = 0; i < 21; i++) A3.M[i] = xm[i][lane];
+                for (int i = 0; i < 21; i++) A3.M[i] = xm[i][el];
 #pragma unroll
-                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][lane]; v3[i] = xq[12 + i][lane]; c3[i] = xk[i][lane]; A3.bias[i] = xb[i][lane]; x3[i] = aw3[i]; cwarm[i] = 0.0f; }
+                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][el]; v3[i] = xq[12 + i][el]; c3[i] = xk[i][el]; A3.bias[i] = xb[i][el]; x3[i] = aw3[i]; cwarm[i] = 0.0f; }
                 arm_tau<float>(q3, v3, c3, A3, tau3);
                 ArmRows<float> r3;
                 arm_row_consts<float>(q3, v3, p.flags, r3);
                 if (coupled3) {
 #pragma unroll
-                    for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][lane];
-                    ap3[2] = xc[19][lane];
+                    for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][el];
+                    ap3[2] = xc[19][el];
                 }
                 const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube, &memo.zones, SO100_PROF_WORK);
                 SO100_PROF_INSUB();
 #pragma unroll
-                for (int i = 0; i < 6; i++) { xa[i][lane] = x3[i]; xa[6 + i][lane] = xcube[i]; aw3[i] = x3[i]; }
-                xa[13][lane] = res;
+                for (int i = 0; i < 6; i++) aw3[i] = x3[i];
+                if (part3 == 0) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { xa[i][el] = x3[i]; xa[6 + i][el] = xcube[i]; }
+                    xa[13][el] = res;
+                }
             }
             // (see "Register pressure" above)
             e = EnvState{}; A = Arm<float>{}; cb = Cube<float>{}; cprep = CubePrep<float>{};
@@ -686,7 +695,10 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         __syncthreads();
     }
     SO100_PROF_FLUSH(10*wave);
-    prof_.flush_wg(wave, lane, env, live);
+    {
+        const int np = 64/p.epw, e3 = blockIdx.x*p.epw + lane/np;      // the contact wave's lanes are grouped per env
+        if (wave == 3) prof_.flush_wg(wave, lane, e3, (lane % np) == 0 && e3 < p.n); else prof_.flush_wg(wave, lane, env, live);
+    }
     if (wave == 0 && live) {
         store_env_state<KIND, FL>(state, p.n, env, e);
         if (ra.T > 0) {

@@ -55,10 +55,11 @@ def _floor_batch(n, seed):
     return qpos, qvel, act
 
 
-@pytest.mark.parametrize("n", [96, 16384 + 96])
+@pytest.mark.parametrize("n", [96, 8192, 16384, 16384 + 96])
 def test_pad_floor_step_vs_oracle(n):
-    """one env step from injected poses with the pads at the floor; n = 96 runs the 4-wave latency kernel (detection on wave 3,
-    Newton on wave 0), n > 16384 the one-wave throughput kernel (the first 96 envs are the injected ones)"""
+    """one env step from injected poses with the pads at the floor; n = 96 runs the 4-wave latency kernel with 16 envs per
+    workgroup (contact wave: 4 cooperating lanes per env), 8192 with 32 (2 lanes per env), 16384 with 64 (one lane per env),
+    n > 16384 the one-wave throughput kernel (the first 96 envs are the injected ones)"""
     m = 96
     qpos, qvel, act = _floor_batch(m, 0)
     sim = _sim(1, n, flags=REFP, solver_iters=4, contact_iters=30, max_episode_steps=0, seed=3)
@@ -146,7 +147,7 @@ def _grasp_batch(n, seed):
     return qpos, qvel, act
 
 
-@pytest.mark.parametrize("n", [64, 16384 + 64])
+@pytest.mark.parametrize("n", [64, 8192, 16384 + 64])
 def test_pad_cube_grasp_vs_oracle(n):
     """BASELINE.json configs[4]: the jaw closes on a cube floating between the pads; arm and cube dofs are coupled in one
     12-unknown solve.  Step by step against the oracle for as long as both see the same pad/cube contact counts."""
