@@ -102,12 +102,13 @@ template <typename T> struct ContactsLds {                  // [record][field][l
 };
 
 // ---- world-frame kinematics of the six joint frames (axis z_k, origin o_k) and of the two jaw links ------------------------
-template <typename T> struct WorldFK { T z[6][3], o[6][3], R4[9], R5[9]; };
+template <typename T> struct WorldFK { T z[6][3], o[6][3], oz[6][3], R4[9], R5[9]; };      // oz_k = o_k x z_k: the linear part of joint k's screw about the world origin
 template <int K, typename T> SO100_HD void wfk_step(const T s[6], const T c[6], T pos[3], T R[9], WorldFK<T>& W) {
     fk_link<K>(s, c, pos, R);
     constexpr int AX = so100g::LINK_AXIS[K];
 #pragma unroll
     for (int i = 0; i < 3; i++) { W.z[K][i] = R[3*i + AX]; W.o[K][i] = pos[i]; }
+    cross(W.o[K], W.z[K], W.oz[K]);
 }
 template <typename T> SO100_HD void world_fk(const T s[6], const T c[6], WorldFK<T>& W) {
     T pos[3] = { T(0), T(0), T(0) };
@@ -126,9 +127,8 @@ template <typename T> SO100_HD void link_spatial(const WorldFK<T>& W, const T x[
     T a[3] = { T(0), T(0), T(0) }, b[3] = { T(0), T(0), T(0) };
 #pragma unroll
     for (int i = 0; i < 6; i++) {
-        T oz[3]; cross(W.o[i], W.z[i], oz);
 #pragma unroll
-        for (int k = 0; k < 3; k++) { a[k] += x[i]*W.z[i][k]; b[k] += x[i]*oz[k]; }
+        for (int k = 0; k < 3; k++) { a[k] += x[i]*W.z[i][k]; b[k] += x[i]*W.oz[i][k]; }
         if (i == 4) {
 #pragma unroll
             for (int k = 0; k < 3; k++) { S4.a[k] = a[k]; S4.b[k] = b[k]; }
@@ -653,8 +653,8 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
                     const bool moves = arm_side && (i < 5 || on5);
-                    const T r[3] = { p[0] - W.o[i][0], p[1] - W.o[i][1], p[2] - W.o[i][2] };
-                    T col[3]; cross(W.z[i], r, col);
+                    T col[3]; cross(W.z[i], p, col);                       // z x (p - o) = z x p + o x z
+                    col[0] += W.oz[i][0]; col[1] += W.oz[i][1]; col[2] += W.oz[i][2];
                     if (ND == 6) { cn_[i] = moves ? col[2] : T(0); c1_[i] = moves ? col[1] : T(0); c2_[i] = moves ? -col[0] : T(0); }
                     else { cn_[i] = moves ? sgn*dot(n, col) : T(0); c1_[i] = moves ? sgn*dot(t1, col) : T(0); c2_[i] = moves ? sgn*dot(t2, col) : T(0); }
                 }
@@ -704,9 +704,8 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             T t = T(0);
 #pragma unroll
             for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
-            const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;
-            T oxf[3]; cross(W.o[i], Fa, oxf);
-            g[i] = (t - tau[i]) + (W.z[i][0]*(Ta[0] - oxf[0]) + W.z[i][1]*(Ta[1] - oxf[1]) + W.z[i][2]*(Ta[2] - oxf[2]));
+            const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;        // z . (T - o x F) = z . T + (o x z) . F
+            g[i] = (t - tau[i]) + (dot(W.z[i], Ta) + dot(W.oz[i], Fa));
         }
         if (MODE == 2) {
 #pragma unroll
