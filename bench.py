@@ -192,8 +192,15 @@ def large_batch_roofline(kind, flags, dev, n=1 << 20, reps=20):
     sim.close()
     gbs = BYTES_PER_ENV_STEP * n / (ms * 1e-3) / 1e9
     tf = FLOP_PER_ENV_STEP * n / (ms * 1e-3) / 1e12
+    # issue slots: VALU wave-instructions per second against what 1024 SIMDs can issue.  22.95 k VALU instructions per lane and env
+    # step (PMC SQ_INSTS_VALU, profiles/r01_c); a SIMD issues a wave64 fp32 instruction every 2 cycles at best, and with the two
+    # waves this kernel keeps resident every 2.27 cycles MEASURED (profiles/r02_simd_share_issue_rate.txt) at ~2.4 GHz.
+    wave_insts_per_s = 22950.0 * (n / (ms * 1e-3)) / 64.0
+    slots = 1024 * 2.4e9 / 2.0
     return {"kernel": "so100_step_fused", "envs": n, "kernel_ms": ms, "env_steps_per_s": n / (ms * 1e-3),
-            "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "valu_tflops": tf, "valu_frac": tf / VALU_PEAK_TFLOPS}
+            "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "valu_tflops": tf, "valu_frac": tf / VALU_PEAK_TFLOPS,
+            "valu_issue_slot_frac": wave_insts_per_s / slots, "valu_issue_slot_frac_of_measured_two_wave_ceiling": wave_insts_per_s / (slots * 2.0 / 2.27),
+            "valu_insts_per_lane_env_step": 22950.0}
 
 
 def main():
