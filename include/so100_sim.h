@@ -82,6 +82,9 @@ typedef struct {
  * state, observation or reward is NaN / inf / beyond 1e10 after a step (e.g. a NaN action), that env's episode ends --
  * done = 1, trunc = 0, reward 0, terminal observation 0 -- it is auto-reset like any other finished episode and bit 128
  * of its "bits" state row is latched.  Other envs of the batch are unaffected. */
+/* "_dev" pointers of THIS struct must be readable / writable by the GPU: device memory, or PINNED HOST memory (hipHostMalloc /
+ * torch pin_memory: mapped into the GPU's address space) -- then the kernel moves the actions / results over the host link itself
+ * and a numpy caller needs no copies at all (So100VecEnv's numpy path). */
 typedef struct {
     const float* act_dev;          /* [N][6]  f32 in [-1,1] (ref: envs/env_base_01.py:77-83)          */
     float*       obs_dev;          /* [N][obs_dim] f32; post-auto-reset observation where done        */
