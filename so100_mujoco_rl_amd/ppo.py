@@ -5,7 +5,7 @@ lr 3e-4, vf_coef 0.5, max_grad_norm 0.5.  NOT SB3's defaults: 4 epochs instead o
 64, rollouts of 64 steps x N envs instead of 2048 x 1 (the batch is 262 144 samples per update at 4096 envs).
 TimeLimit truncations are bootstrapped by the collector exactly as SB3 does (rewards += gamma V(terminal_obs)), so
 `dones` below ends the GAE recursion with the right target for both terminations and truncations.  On a GPU the
-update is replayed from two captured hipGraphs (GAE pass, minibatch step): it is launch-bound otherwise.
+update CAN be replayed from two captured hipGraphs (GAE pass, minibatch step; use_graph=True): opt-in, see __init__.
 The network's state_dict keys equal SB3's ActorCriticPolicy keys, so checkpoints and RolloutCollector.load_policy()
 interoperate with an SB3 policy."""
 import os
@@ -41,7 +41,7 @@ class ActorCritic(nn.Module):
 
 class PPO:
     def __init__(self, obs_dim, device, lr=3e-4, gamma=0.99, gae_lambda=0.95, clip=0.2, epochs=4, minibatch=32768,
-                 vf_coef=0.5, max_grad_norm=0.5, seed=0, use_graph=True):
+                 vf_coef=0.5, max_grad_norm=0.5, seed=0, use_graph=False):
         torch.manual_seed(seed)
         self.net = ActorCritic(obs_dim).to(device)
         on_gpu = torch.device(device).type == "cuda"
@@ -51,6 +51,10 @@ class PPO:
         # One PPO update is ~40 minibatch steps of ~100 tiny kernels each plus a 64-step GAE recursion: launch-bound in eager
         # mode (~60 ms for a 262 144-sample batch).  With use_graph the GAE pass and the minibatch step are captured once as
         # hipGraphs over static buffers and replayed (~5 ms); the arithmetic is the same.
+        # OPT-IN since round 2: over hundreds of updates the replayed learner has shown policy collapses (Env01 / Env05, several seeds,
+        # worst together with the collector's truncation bootstrap) that the eager learner does not show on the same seeds, although
+        # one replayed update equals one eager update (tests/test_export.py); cause not found.  With the rollout at 17 .. 120 M
+        # env-steps/s and the eager update at ~60 ms the end-to-end difference is a few per cent.
         self.use_graph = use_graph and on_gpu and os.environ.get("SO100_PPO_GRAPH", "1") != "0"
         self._g = None
 
