@@ -94,6 +94,7 @@ int hc_boxbox_f(const double* cA, const double* RA, const double* hA, const doub
 void hc_cdbg_trace(int on) { g_dbg_cnewton_trace = on; }
 void hc_cdbg_counters(long* out) { out[0] = g_dbg_cnewton_calls; out[1] = g_dbg_cnewton_iters; out[2] = g_dbg_cnewton_ls; }
 long hc_cdbg_passes(void) { return g_dbg_cnewton_passes; }
+int hc_contact_id_hash(int id) { return contact_id_hash(id); }
 }
 
 // ---- the full task layer (so100_task.hpp) on the host, fp32, one env ------------------------------------------------

@@ -174,3 +174,15 @@ def test_active_set_memory_over_whole_env_steps(H):
     assert compared > 40
     assert worst < 2e-5                                      # measured 1e-6: 2e-5 rad / m, 2e-3 per second
     assert (p1 - p0) < 3.5*(c1 - c0)[0]                      # row passes per solve (7.2 before the memory; 2.9 with it)
+
+
+def test_feature_hash_of_the_active_set_memory(H):
+    """the one-byte memory entry keeps a 4-bit hash of the contact's feature id (pad/floor: 8 * pad + corner): the same corner of
+    different pads must hash differently (two pads of a jaw lying flat touch with the same corners), and so must the corners of
+    one pad; collisions that remain (different corners of different pads) only cost a worse first guess"""
+    h = lambda i: H.hc_contact_id_hash(i)
+    for corner in range(8):
+        assert len({h(8*g + corner) for g in range(8)}) == 8
+    for g in range(8):
+        assert len({h(8*g + c) for c in range(8)}) == 8
+    assert all(0 <= h(i) < 16 for i in range(256))
