@@ -13,17 +13,18 @@ __global__ void __launch_bounds__(64) k_run(const float* q0, float* out, long lo
     Cube<float> cb{}; cb.pos[0] = 0.2f; cb.pos[1] = -0.2f; cb.pos[2] = 0.0099f; cb.quat[0] = 1.0f;
     const float ap[3] = {0, 0, 0};
     Arm<float> A; float res = 0; int st[3] = {0, 0, 0}; int nmax = 0;
+    ContactsPriv<float> cs; int zones = -1;                // the solver's active-set memory, carried from substep to substep
     // settle first (untimed), then time
     const int settle = mode == 2 ? 4800 : 960;
     for (int s = 0; s < settle; s++) {
         if (mode == 2 && (s & 15) == 0) for (int i = 0; i < 6; i++) ctrl[i] = q[i];       // Env01's ctrl = measured angle + 0 action: the arm sags onto the floor
-        substep_with_pads<float>(q, v, qc, ctrl, ff, fl, aw, cb, ap, flags, 2, iters, A, (s & 15) == 0, dq, &res, st);
+        substep_with_pads<float>(q, v, qc, ctrl, ff, fl, aw, cb, ap, flags, 2, iters, A, (s & 15) == 0, dq, &res, cs, zones, st);
     }
     res = 0;
     const long long c0 = __builtin_readcyclecounter();
     for (int s = 0; s < nsub; s++) {
         if (mode == 2 && (s & 15) == 0) for (int i = 0; i < 6; i++) ctrl[i] = q[i];
-        substep_with_pads<float>(q, v, qc, ctrl, ff, fl, aw, cb, ap, flags, 2, iters, A, (s & 15) == 0, dq, &res, st); nmax = st[0] > nmax ? st[0] : nmax;
+        substep_with_pads<float>(q, v, qc, ctrl, ff, fl, aw, cb, ap, flags, 2, iters, A, (s & 15) == 0, dq, &res, cs, zones, st); nmax = st[0] > nmax ? st[0] : nmax;
     }
     const long long c1 = __builtin_readcyclecounter();
     if (t == 0) cyc[0] = c1 - c0;
