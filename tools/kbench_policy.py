@@ -14,4 +14,4 @@ e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=T
 torch.cuda.synchronize(); e0.record()
 for i in range(200): sim.policy_forward(sim.obs, act, i, rollout_row=row)
 e1.record(); torch.cuda.synchronize()
-print(f"N={n} kernel={os.environ.get('SO100_POLICY_KERNEL', 'mfma')}: policy kernel {e0.elapsed_time(e1)/200*1e3:.1f} us")
+print(f"N={n}: policy kernel (matrix-core) {e0.elapsed_time(e1)/200*1e3:.1f} us")

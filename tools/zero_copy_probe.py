@@ -1,5 +1,5 @@
 """Probe: the step kernel reading actions from / writing results to PINNED HOST memory directly (one kernel node, no copy nodes)
-against the current VecEnv round trip (H2D + kernel + 7 D2H copies in one hipGraph).   python tools/zero_copy_probe.py [envs]"""
+against the staged round trip (H2D + kernel + 7 D2H copies; So100VecEnv(use_graph=False)).   python tools/zero_copy_probe.py [envs]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -44,8 +44,8 @@ for flags, name in ((F_CUBE_PINNED, "free"), (F_NOPADS, "nopads")):
             o = h_obs.numpy().copy(); r = h_rew.numpy().copy(); d = h_done.numpy().astype(bool)
         dt = (time.perf_counter() - t0)/300
         print(f"{name:7s} N={n}: zero-copy {mode}: {dt*1e6:7.1f} us per step (incl. host-side copies of actions / obs / rew / done)")
-    env = So100VecEnv("Env01-v1", n, flags=flags, seed=1); env.reset()
+    env = So100VecEnv("Env01-v1", n, flags=flags, seed=1, use_graph=False); env.reset()
     for it in range(20): env.step_async(a); env.step_wait()
     t0 = time.perf_counter()
     for it in range(300): env.step_async(a); env.step_wait()
-    print(f"{name:7s} N={n}: So100VecEnv today:  {(time.perf_counter() - t0)/300*1e6:7.1f} us per step")
+    print(f"{name:7s} N={n}: So100VecEnv staged:   {(time.perf_counter() - t0)/300*1e6:7.1f} us per step")
