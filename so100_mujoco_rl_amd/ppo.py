@@ -51,10 +51,12 @@ class PPO:
         # One PPO update is ~40 minibatch steps of ~100 tiny kernels each plus a 64-step GAE recursion: launch-bound in eager
         # mode (~60 ms for a 262 144-sample batch).  With use_graph the GAE pass and the minibatch step are captured once as
         # hipGraphs over static buffers and replayed (~5 ms); the arithmetic is the same.
-        # OPT-IN since round 2: over hundreds of updates the replayed learner has shown policy collapses (Env01 / Env05, several seeds,
-        # worst together with the collector's truncation bootstrap) that the eager learner does not show on the same seeds, although
-        # one replayed update equals one eager update (tests/test_export.py); cause not found.  With the rollout at 17 .. 120 M
-        # env-steps/s and the eager update at ~60 ms the end-to-end difference is a few per cent.
+        # OPT-IN since round 2.  What went wrong with it as the default: the simulator's kernels read the learner's LIVE parameters
+        # (RolloutCollector.load_policy aliases them) and are launched on the raw current stream; the next rollout did not wait for
+        # the end of the last replayed minibatch step (graph work is not joined to the legacy null stream the way eager work is),
+        # so it sampled with half-updated weights -> log-probs inconsistent with the actions -> policy collapse after ~60 updates
+        # (Env01 / Env05, several seeds; never in eager mode; gone with a device synchronisation after the replays, or with cloned
+        # weights: tools/ppo_graph_check.py).  update() now ends the replayed path with torch.cuda.synchronize().
         self.use_graph = use_graph and on_gpu and os.environ.get("SO100_PPO_GRAPH", "1") != "0"
         self._g = None
 
@@ -134,5 +136,6 @@ class PPO:
                 else:
                     S["idx"] = perm[i:i + mb]
                     self.opt.zero_grad(set_to_none=True); self._step()
-        if not graph: S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
+        if graph: torch.cuda.synchronize()                 # the replays must have finished before anyone reads the parameters (see __init__)
+        else: S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
         return {"value_loss": S["vl"].item(), "mean_reward": S["rewards"].mean().item()}
