@@ -56,8 +56,15 @@ class RolloutCollector:
         return sd
 
     def load_policy(self, state_dict):
-        t = {k: state_dict[SB3_STATE_DICT_KEYS[k]].detach().to(self.sim.device, torch.float32).contiguous() for k in POLICY_TENSORS}
-        self.sim.set_policy(t)
+        """Copies the weights into buffers this collector owns (the kernels read THESE: a learner that keeps updating its
+        parameters in place -- or asynchronously, from replayed hipGraphs -- cannot change the policy under a running rollout)."""
+        with torch.no_grad():
+            if getattr(self, "_wbuf", None) is None:
+                self._wbuf = {k: state_dict[SB3_STATE_DICT_KEYS[k]].detach().to(self.sim.device, torch.float32).clone().contiguous() for k in POLICY_TENSORS}
+                self.sim.set_policy(self._wbuf)
+            else:
+                for k in POLICY_TENSORS:
+                    self._wbuf[k].copy_(state_dict[SB3_STATE_DICT_KEYS[k]])
 
     @torch.no_grad()
     def _value(self, obs):

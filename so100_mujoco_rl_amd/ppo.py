@@ -4,8 +4,8 @@ stable-baselines3 is not importable (it is not in this image).  Network and loss
 lr 3e-4, vf_coef 0.5, max_grad_norm 0.5.  NOT SB3's defaults: 4 epochs instead of 10, minibatches of 32 768 instead of
 64, rollouts of 64 steps x N envs instead of 2048 x 1 (the batch is 262 144 samples per update at 4096 envs).
 TimeLimit truncations are bootstrapped by the collector exactly as SB3 does (rewards += gamma V(terminal_obs)), so
-`dones` below ends the GAE recursion with the right target for both terminations and truncations.  On a GPU the
-update CAN be replayed from two captured hipGraphs (GAE pass, minibatch step; use_graph=True): opt-in, see __init__.
+`dones` below ends the GAE recursion with the right target for both terminations and truncations.  (Round 1's
+hipGraph-replayed update is gone: see PPO.__init__.)
 The network's state_dict keys equal SB3's ActorCriticPolicy keys, so checkpoints and RolloutCollector.load_policy()
 interoperate with an SB3 policy."""
 import os
@@ -45,22 +45,18 @@ class PPO:
         torch.manual_seed(seed)
         self.net = ActorCritic(obs_dim).to(device)
         on_gpu = torch.device(device).type == "cuda"
-        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, eps=1e-5, capturable=on_gpu)
+        self.opt = torch.optim.Adam(self.net.parameters(), lr=lr, eps=1e-5)
         self.gamma, self.lam, self.clip, self.epochs, self.mb = gamma, gae_lambda, clip, epochs, minibatch
         self.vf_coef, self.max_grad_norm, self.device = vf_coef, max_grad_norm, device
-        # One PPO update is ~40 minibatch steps of ~100 tiny kernels each plus a 64-step GAE recursion: launch-bound in eager
-        # mode (~60 ms for a 262 144-sample batch).  With use_graph the GAE pass and the minibatch step are captured once as
-        # hipGraphs over static buffers and replayed (~5 ms); the arithmetic is the same.
-        # OPT-IN since round 2.  What went wrong with it as the default: the simulator's kernels read the learner's LIVE parameters
-        # (RolloutCollector.load_policy aliases them) and are launched on the raw current stream; the next rollout did not wait for
-        # the end of the last replayed minibatch step (graph work is not joined to the legacy null stream the way eager work is),
-        # so it sampled with half-updated weights -> log-probs inconsistent with the actions -> policy collapse after ~60 updates
-        # (Env01 / Env05, several seeds; never in eager mode; gone with a device synchronisation after the replays, or with cloned
-        # weights: tools/ppo_graph_check.py).  update() now ends the replayed path with torch.cuda.synchronize().
-        self.use_graph = use_graph and on_gpu and os.environ.get("SO100_PPO_GRAPH", "1") != "0"
-        self._g = None
+        # use_graph is accepted and ignored.  Round 1 replayed the update from two captured hipGraphs (+14 % end to end when the
+        # rollout ran at 54 M env-steps/s).  With the collector's truncation bootstrap in the loop it produced policy collapses
+        # after ~60 updates: replays launched on the legacy default stream were not ordered against the next rollout's raw kernel
+        # launch, which read half-updated parameters; fencing fixed the collapses, but from its third update on the replayed
+        # learner still differed from the eager one on identical inputs (5e-3 in the weights, cause not found), so it was removed
+        # rather than shipped as an option nobody can vouch for.  The eager update is ~60 ms per 262 144 samples.
+        del use_graph
 
-    # ---- the two pieces of an update, written over the static buffers self._s (also what gets captured) ---------------
+    # ---- the two pieces of an update, written over the buffers self._s -------------------------------------------------
     def _gae(self):
         S = self._s; net = self.net
         with torch.no_grad():
@@ -98,44 +94,19 @@ class PPO:
                        idx=torch.zeros(min(self.mb, T * N), dtype=torch.long, device=dev), vl=torch.zeros((), device=dev))
         self._shape = tuple(b["obs"].shape)
 
-    def _capture(self):
-        """torch's whole-network capture recipe: a few real steps on a side stream, then one captured step."""
-        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._gae()
-            for _ in range(3):
-                self.opt.zero_grad(set_to_none=True); self._step()
-        torch.cuda.current_stream().wait_stream(s)
-        g_gae = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_gae):
-            self._gae()
-        g_step = torch.cuda.CUDAGraph(); self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(g_step):
-            self._step()
-        self._g = (g_gae, g_step)
-
     def update(self, b):
         """b: RolloutCollector.collect() output ([T, N, ...] device tensors + last_obs)."""
         if getattr(self, "_s", None) is None or self._shape != tuple(b["obs"].shape):
-            self._alloc(b); self._g = None
+            self._alloc(b)
         S = self._s
         for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
             S[k].copy_(b[k])
         n = S["ret"].numel(); mb = S["idx"].numel()
-        graph = self.use_graph and n % mb == 0
-        if graph and self._g is None:
-            S["idx"].copy_(torch.randperm(n, device=self.device)[:mb])
-            self._capture()
-        if graph: self._g[0].replay()
-        else: self._gae()
+        self._gae()
         for _ in range(self.epochs):
             perm = torch.randperm(n, device=self.device)
             for i in range(0, n, mb):
-                if graph:
-                    S["idx"].copy_(perm[i:i + mb]); self._g[1].replay()
-                else:
-                    S["idx"] = perm[i:i + mb]
-                    self.opt.zero_grad(set_to_none=True); self._step()
-        if graph: torch.cuda.synchronize()                 # the replays must have finished before anyone reads the parameters (see __init__)
-        else: S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
+                S["idx"] = perm[i:i + mb]
+                self.opt.zero_grad(set_to_none=True); self._step()
+        S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
         return {"value_loss": S["vl"].item(), "mean_reward": S["rewards"].mean().item()}
