@@ -1,7 +1,7 @@
 """Cycle accounting of the persistent rollout kernel's phases (waves 0-3 of workgroup 0).
 Build the instrumented side library HERE (no GPU needed), then run on the GPU box:
     python tools/rollout_prof.py build
-    gpurun -- python tools/rollout_prof.py [free|arm|nopads|ref|c5] [random|resting]
+    gpurun -- python tools/rollout_prof.py [free|arm|nopads|ref|c5] [random|resting|held]
 The product library is untouched (the instrumentation is compiled out without -DSO100_ROLLOUT_PROF)."""
 import ctypes as C, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,8 +33,10 @@ flags = {"free": F_CUBE_PINNED, "arm": F_FRICTIONLOSS | F_LIMITS | F_CUBE_PINNED
 n, T = 4096, 64
 sim = So100Sim(1, n, flags=flags, seed=1); sim.reset()
 sd = RolloutCollector.random_policy_state(sim.obs_dim, sim.device, seed=0)
-if mode == "resting":                       # zero action: Env01's ctrl = measured angle lets every arm sag onto the floor and rest there
+if mode in ("resting", "held"):             # zero action: Env01's ctrl = measured angle lets every arm sag onto the floor and rest there
     sd["action_net.weight"].zero_(); sd["action_net.bias"].zero_(); sd["log_std"].fill_(-30.0)
+if mode == "held":                          # a constant lifting action on the shoulder: no arm touches the floor (the cost of detection alone)
+    sd["action_net.bias"][1] = -1.0
 sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
 buf = torch.empty(T, n, sim.obs_dim + 10, device="cuda")
 for i in range(4):
