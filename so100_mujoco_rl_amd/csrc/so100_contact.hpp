@@ -821,19 +821,22 @@ __device__ unsigned long long so100_cstats[8];          // calls, iterations, li
 #endif
 
 // Newton on the primal problem.  x: warm start in, solution out.  Returns the size of the last Newton step when the
-// iteration budget ran out before the step fell under the tolerance (0 otherwise): the solver residual a caller can watch.
+// iteration budget ran out before the solve ended (0 otherwise): the solver residual a caller can watch.
 //
-// One pass over the rows per iteration in the common case: eval<2> gives gradient and Hessian at x, the full Newton step is
-// taken, and the NEXT iteration's eval<2> at x + dx doubles as its acceptance test -- the step stands if the directional
-// derivative there, phi'(1) = g(x + dx).dx, is at most half of |phi'(0)| (phi convex with phi' continuous and piecewise
-// linear: no row changed zone => phi'(1) = 0).  Only when a step overshoots (many rows switching on: an impact) is the exact
-// line search run (safeguarded Newton on phi', one derivative pass per trial).  No cost values are compared anywhere:
-// 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost DIFFERENCE of the size of a Newton decrement is below the
-// round-off of the two costs.
-// Stopping in fp32.  The pad rows are stiff (1/R = 3e3 against M ~ 0.1): a row's force is D * jar with jar = J.x + b a small
-// difference of O(10) terms, so forces carry a relative round-off of ~3e-4 and the gradient never falls below that floor.  The
-// iteration therefore also ends when a step of at most 1e-3 relative size brings no further progress in the scaled gradient
-// norm E = g'diag(M)^-1 g (quadratic convergence would have divided it by far more than 4): converged to working precision.
+// 1. (warm) One full step on the quadratic of the REMEMBERED active set (eval<2, FORCED>): see the comment in the body.
+// 2. A plain pass at the new point tells which set x selects.  Same set as the quadratic that produced x by a full step =>
+//    x is the minimiser of the true cost (the exact convergence test of a piecewise-quadratic problem); one more step on the
+//    same set's Hessian removes the first step's round-off and the solve ends: two row passes.
+// 3. Otherwise safeguarded Newton: eval<2> at the trial point x + dx gives gradient and Hessian there at once -- the step
+//    stands if the set did not change over it (-> 2.), if the merit E = g'diag(M)^-1 g fell to a quarter, or if the slope
+//    phi'(1) = g(x + dx).dx is at most half of |phi'(0)| (phi convex, phi' continuous and piecewise linear).  Only when a step
+//    overshoots (many rows switching on: an impact) the exact line search runs (safeguarded Newton on phi', one derivative
+//    pass per trial).  No cost values are compared anywhere: 1/2 x'Mx reaches 1e5 during an impact, so in fp32 a cost
+//    DIFFERENCE of the size of a Newton decrement is below the round-off of the two costs.
+// Fallback stop in fp32.  The pad rows are stiff (1/R = 3e3 against M ~ 0.1): a row's force is D * jar with jar = J.x + b a
+// small difference of O(10) terms, so forces carry a relative round-off of ~3e-4 and rows at a kink may flicker between
+// passes.  TWO consecutive steps of at most 1e-3 relative size without progress in E end the solve (one is not enough: x may
+// sit at a kink whose other side wants to go elsewhere).
 template <int ND, typename T> SO100_HD T grad_merit(const T g[ND]) {
     T E = T(0);
 #pragma unroll

@@ -254,6 +254,18 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         if (wave == 3 && pads && any3) {
             if (cs3.n > 0) {
                 float q3[6], v3[6], c3[6], tau3[6], x3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
+                // the joint frames again, from the published sin / cos (270 instructions, only in waves that have a contact): keeping
+                // the 72 floats of the detection's copy alive across the barrier costs every wave's code registers (one allocation for
+                // the whole kernel) and showed up as scratch traffic in the arm / cube legs
+#pragma unroll
+                for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][el]; A3.c[i] = xq[6 + i][el]; }
+                world_fk<float>(A3.s, A3.c, W3);
+                if (padcube) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) cpos3[i] = xc[i][el];
+                    float qn[4] = { xc[3][el], xc[4][el], xc[5][el], xc[6][el] };
+                    quat_normalize(qn); quat_to_mat(qn, Rc3);
+                }
 #pragma unroll
                 for (int i = 0; i < 21; i++) A3.M[i] = xm[i][el];
 #pragma unroll
