@@ -237,3 +237,21 @@ def test_contact_kernels_agree_with_each_other(flags):
         # to the solver tolerance per substep, and to the make / break bound of the module docstring over three env steps
         assert dq[same].max() < 2e-4 and dv[same].max() < 1e-1, (name, float(dq[same].max()), float(dv[same].max()))
         assert dq[same].median() < 5e-6 and dv[same].median() < 5e-4, (name, float(dq[same].median()), float(dv[same].median()))
+
+
+@pytest.mark.parametrize("flags", [REFP, C5])
+def test_tail_workgroups_with_pad_contacts(flags):
+    """batch sizes that are not a multiple of the envs-per-workgroup count (16 here): env by env the results must be BIT-IDENTICAL
+    to the same envs inside a 256-env batch -- the contact wave's lane groups that belong to no env must not matter"""
+    for n in (1, 17, 130):
+        big = _sim(1, 256, flags=flags, seed=5, max_episode_steps=25); small = _sim(1, n, flags=flags, seed=5, max_episode_steps=25)
+        assert torch.equal(big.reset()[:n], small.reset())
+        g = torch.Generator(device="cuda"); g.manual_seed(3); touched = 0
+        for t in range(40):
+            a = torch.rand(256, 6, device="cuda", generator=g)*2 - 1; a[:, 1] = 1.0      # shoulder down: the pads reach the floor within a few steps
+            o1, r1, d1, _ = big.step(a); o2, r2, d2, _ = small.step(a[:n].contiguous())
+            assert torch.equal(o1[:n], o2) and torch.equal(r1[:n], r2) and torch.equal(d1[:n], d2), (n, t)
+            touched = max(touched, int((small.get_field("contact_stat", dtype=torch.int32) & 255).max()))
+        q1, v1 = big.get_state(); q2, v2 = small.get_state()
+        assert torch.equal(q1[:, :n], q2) and torch.equal(v1[:, :n], v2) and touched >= 2
+        big.close(); small.close()
