@@ -255,3 +255,40 @@ def test_tail_workgroups_with_pad_contacts(flags):
         q1, v1 = big.get_state(); q2, v2 = small.get_state()
         assert torch.equal(q1[:, :n], q2) and torch.equal(v1[:, :n], v2) and touched >= 2
         big.close(); small.close()
+
+
+@pytest.mark.parametrize("kind,flags", [(1, REFP), (2, C5), (6, REFP)])
+def test_whole_env_steps_with_pad_contacts_vs_oracle(kind, flags):
+    """the full path -- task layer + physics with pad contacts -- of Env01 / Env02 / Env06 against the oracle's env step (its
+    Newton solver) from reset, arms driven down until the pads are on the floor.  An env counts until a contact event lands a
+    substep apart in fp32 and fp64 (its observation then jumps by > 1e-3); most envs never do within the run."""
+    n, steps = 48, (40 if kind == 1 else 16)                  # (Env01 starts higher above the table)
+    rs = np.random.RandomState(kind)
+    sim = _sim(kind, n, flags=flags, solver_iters=4, contact_iters=30, max_episode_steps=0, seed=11)
+    orc = [O.OracleEnv(kind, flags=flags, iters=-1, seed=11, env_id=i) for i in range(n)]
+    for e in orc:
+        e.e.max_episode_steps = 0
+    inj = rs.random_sample((n, 16)).astype(np.float32)
+    og = sim.reset(inject=torch.from_numpy(inj).cuda()).cpu().numpy()
+    oo = np.stack([e.reset(inject=inj[i]) for i, e in enumerate(orc)])
+    np.testing.assert_allclose(og, oo, rtol=0, atol=1e-6)
+    alive = np.ones(n, bool); worst = np.zeros(n); touched = np.zeros(n, bool)
+    for t in range(steps):
+        a = rs.uniform(-1, 1, (n, 6)).astype(np.float32); a[:, 1] = 1.0                 # shoulder down
+        inj = rs.random_sample((n, 16)).astype(np.float32)
+        ob, rw, dn, _ = sim.step(torch.from_numpy(a).cuda(), inject=torch.from_numpy(inj).cuda())
+        ob = ob.cpu().numpy(); rw = rw.cpu().numpy()
+        assert np.isfinite(ob).all() and np.isfinite(rw).all()
+        touched |= (sim.get_field("contact_stat", dtype=torch.int32).cpu().numpy() & 255) > 0
+        for i, e in enumerate(orc):
+            if not alive[i]:
+                continue
+            o, r = e.step(a[i], inject=inj[i], autoreset=True)[:2]
+            err = max(np.abs(ob[i] - o).max(), abs(rw[i] - r))
+            if err > 1e-3:
+                alive[i] = False
+            else:
+                worst[i] = max(worst[i], err)
+    assert touched.mean() > (0.1 if kind == 1 else 0.5)      # the pads did reach the floor (Env01 starts high: fewer of its arms get there)
+    assert alive.mean() > 0.6                                # most envs never saw a contact event a substep apart
+    assert np.median(worst[alive]) < 2e-5 and np.percentile(worst[alive], 90) < 2e-4
