@@ -471,7 +471,7 @@ static int add_row(so100o_data* d, int type, int id, const double* J, double pos
  * ---------------------------------------------------------------------------------------------- */
 /* mjc_PlaneBox against the floor z = 0 (normal +z): every corner that is at / below the plane AND below the box centre, in
  * corner order, at most 4; contact point midway between the corner and the plane */
-int so100o_plane_box(const double c[3], const double R[9], const double h[3], double pos[4][3], double dist[4]) {
+static int plane_box_ids(const double c[3], const double R[9], const double h[3], double pos[4][3], double dist[4], int corner_id[4]) {
     int cnt = 0;
     const double cdist = c[2];
     for (int k = 0; k < 8 && cnt < 4; k++) {
@@ -481,9 +481,13 @@ int so100o_plane_box(const double c[3], const double R[9], const double h[3], do
         if (cdist + ldist > 0 || ldist > 0) continue;
         dist[cnt] = cdist + ldist;
         pos[cnt][0] = corner[0] + c[0]; pos[cnt][1] = corner[1] + c[1]; pos[cnt][2] = corner[2] + c[2] - dist[cnt]*0.5;
+        if (corner_id) corner_id[cnt] = k;
         cnt++;
     }
     return cnt;
+}
+int so100o_plane_box(const double c[3], const double R[9], const double h[3], double pos[4][3], double dist[4]) {
+    return plane_box_ids(c, R, h, pos, dist, NULL);
 }
 
 /* Box-box, in the manner of mjc_BoxBox: separating-axis test over the 15 candidate axes, then
@@ -629,7 +633,7 @@ static void jac_point_dir(const so100o_data* d, int b, const double p[3], const 
     }
 }
 
-static int add_contact(const so100o_model* m, so100o_data* d, int kind, int geom, int b1, int b2, const double pos[3],
+static int add_contact(const so100o_model* m, so100o_data* d, int kind, int geom, int feat, int b1, int b2, const double pos[3],
                        const double normal[3], double dist, double mu, const double solref[2], const double solimp[5]) {
     /* the product's contact budget (csrc/so100_contact.hpp: MAXPADC) counts PAD contacts, in detection order pad/floor by
      * pad then pad/cube by pad; the cube's own <= 4 floor contacts are outside it */
@@ -638,7 +642,7 @@ static int add_contact(const so100o_model* m, so100o_data* d, int kind, int geom
         if ((m->max_contacts > 0 && npad >= m->max_contacts) || d->ncon >= SO100O_MAXCON) { d->ncon_dropped++; return -1; }
     }
     so100o_contact* c = &d->con[d->ncon];
-    c->b1 = b1; c->b2 = b2; c->kind = kind; c->geom = geom; c->dist = dist; c->mu = mu;
+    c->b1 = b1; c->b2 = b2; c->kind = kind; c->geom = geom; c->feat = feat; c->dist = dist; c->mu = mu;
     memcpy(c->pos, pos, sizeof c->pos); memcpy(c->solref, solref, sizeof c->solref); memcpy(c->solimp, solimp, sizeof c->solimp);
     /* mju_makeFrame: t1 = (0,1,0) if |n_y| < 0.5 else (0,0,1), orthogonalised against n; t2 = n x t1 */
     double* f = c->frame;
@@ -699,19 +703,20 @@ static void make_constraints(const so100o_model* m, so100o_data* d, unsigned fla
     if ((flags & SO100O_F_FLOOR) && !(flags & SO100O_F_CUBE_PINNED)) {
         double hs[3] = { SO100_CUBE_HALF, SO100_CUBE_HALF, SO100_CUBE_HALF }, pos[4][3], dist[4], ref[2], imp[5], mu;
         mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->def_solref, m->def_solimp, m->def_friction, ref, imp, &mu);
-        const int n = so100o_plane_box(d->xpos[CUBE], d->xmat[CUBE], hs, pos, dist);
-        for (int k = 0; k < n; k++) add_contact(m, d, 0, 0, 0, CUBE, pos[k], nz, dist[k], mu, ref, imp);
+        int cid[4];
+        const int n = plane_box_ids(d->xpos[CUBE], d->xmat[CUBE], hs, pos, dist, cid);
+        for (int k = 0; k < n; k++) add_contact(m, d, 0, 0, 128 + cid[k], 0, CUBE, pos[k], nz, dist[k], mu, ref, imp);
     }
     if (flags & SO100O_F_PADS_FLOOR) {
         double ref[2], imp[5], mu;
         mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->pad_solref, m->pad_solimp, m->pad_friction, ref, imp, &mu);
         for (int g = 0; g < SO100O_NPAD; g++) {
             const int b = m->pad_body[g];
-            double c[3], v[3], pos[4][3], dist[4];
+            double c[3], v[3], pos[4][3], dist[4]; int cid[4];
             mat_vec3(v, d->xmat[b], m->pad_pos[g]);
             for (int k = 0; k < 3; k++) c[k] = d->xpos[b][k] + v[k];
-            const int n = so100o_plane_box(c, d->xmat[b], m->pad_size[g], pos, dist);
-            for (int k = 0; k < n; k++) add_contact(m, d, 1, g, 0, b, pos[k], nz, dist[k], mu, ref, imp);
+            const int n = plane_box_ids(c, d->xmat[b], m->pad_size[g], pos, dist, cid);
+            for (int k = 0; k < n; k++) add_contact(m, d, 1, g, 8*g + cid[k], 0, b, pos[k], nz, dist[k], mu, ref, imp);
         }
     }
     if ((flags & SO100O_F_PADS_CUBE) && !(flags & SO100O_F_CUBE_PINNED)) {
@@ -723,7 +728,7 @@ static void make_constraints(const so100o_model* m, so100o_data* d, unsigned fla
             mat_vec3(v, d->xmat[b], m->pad_pos[g]);
             for (int k = 0; k < 3; k++) c[k] = d->xpos[b][k] + v[k];
             const int n = so100o_box_box(c, d->xmat[b], m->pad_size[g], d->xpos[CUBE], d->xmat[CUBE], hs, pos, nrm, dist);
-            for (int k = 0; k < n; k++) add_contact(m, d, 2, g, b, CUBE, pos[k], nrm, dist[k], mu, ref, imp);
+            for (int k = 0; k < n; k++) add_contact(m, d, 2, g, 64 + 8*g + k, b, CUBE, pos[k], nrm, dist[k], mu, ref, imp);
         }
     }
 }

@@ -40,7 +40,7 @@ class Model(C.Structure):
 
 
 class Contact(C.Structure):
-    _fields_ = [("b1", C.c_int), ("b2", C.c_int), ("kind", C.c_int), ("geom", C.c_int),
+    _fields_ = [("b1", C.c_int), ("b2", C.c_int), ("kind", C.c_int), ("geom", C.c_int), ("feat", C.c_int),
                 ("pos", d_ * 3), ("frame", d_ * 9), ("dist", d_), ("mu", d_), ("solref", d_ * 2), ("solimp", d_ * 5),
                 ("efc0", C.c_int)]
 

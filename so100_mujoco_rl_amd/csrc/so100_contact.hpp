@@ -48,6 +48,12 @@ enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY,
 // The solver leaves (hash(id) << 4 | final mask), one byte, of every record in the store's "previous" list for the next substep's
 // detection (4-bit hash: distinct for the same corner of different pads; a collision only costs a worse first guess).
 SO100_HD int contact_id_hash(int id) { return (id ^ (id >> 4)) & 15; }
+// 32-bit mix of a feature id; a contact SET's signature is the wrapping sum of it over the set's PAD contacts (order-free: the
+// cooperating lanes add their shares).  Parity tests compare it with the same sum over the oracle's contact list (so100o_contact.feat).
+SO100_HD int contact_id_mix(int id) {
+    unsigned h = (unsigned)(id + 1)*0x9E3779B1u; h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;
+    return (int)h;
+}
 
 // Cooperative lanes.  When a wavefront holds fewer envs than lanes (the multi-wave kernels spread small batches over all CUs: 16 or
 // 32 envs per 64-lane wave), the contact wave gives each env a group of `nparts` = 4 or 2 ADJACENT lanes (a quad, or half of one):
@@ -75,6 +81,13 @@ template <class Store> SO100_HD int coop_first(const Store& cs, int v) {
         else if (cs.nparts == 2) v = __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true);   // quad_perm [0,0,2,2]
     }
 #endif
+    return v;
+}
+template <class Store> SO100_HD int coop_sum_int(const Store& cs, int v) {          // wrapping sum (unsigned arithmetic)
+    if constexpr (Store::COOP) {
+        if (cs.nparts >= 2) v = (int)((unsigned)v + (unsigned)quad_xor1(v));
+        if (cs.nparts == 4) v = (int)((unsigned)v + (unsigned)quad_xor2(v));
+    }
     return v;
 }
 template <class Store> SO100_HD int coop_or(const Store& cs, int v) {
@@ -522,6 +535,16 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
     }
     if (cs.n > 0) cs.prev_n = cs.n;                            // (the solve fills the list: every row pass leaves id | final mask per record)
     return coupled;
+}
+// signature of the set of PAD contacts in the store (cube/floor records, kind 0, are the cube block's business): see contact_id_mix
+template <class Store> SO100_HD int contact_signature(const Store& cs) {
+    unsigned sig = 0u;
+#pragma unroll 1
+    for (int s = cs.part; s < cs.n; s += cs.nparts) {
+        const int code = (int)cs.get(s, C_KIND);
+        if ((code & 7) != 0) sig += (unsigned)contact_id_mix((code >> 3) & 255);
+    }
+    return coop_sum_int(cs, (int)sig);
 }
 
 // ---- N x N SPD systems, N = 6 or 12: LDL^T in place on the packed lower triangle -----------------------------------------
@@ -1047,7 +1070,8 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
 }
 
 // One whole substep of one env with the pad-contact flags on, single lane (the one-wave step kernel and the host tests; the
-// multi-wave kernels run the same stages spread over their waves).  stat (optional): [0] contacts, [1] coupled, [2] dropped.
+// multi-wave kernels run the same stages spread over their waves).  stat (optional): [0] contacts, [1] coupled, [2] dropped,
+// [3] signature of the pad-contact set (contact_signature).
 // cs / zones: the caller's contact store and active-set memory, kept from substep to substep (zones = -1 to start with).
 template <typename T>
 SO100_HD void substep_with_pads(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6], T fl[6], T aw[6], Cube<T>& cube, const T applied[3],
@@ -1064,7 +1088,7 @@ SO100_HD void substep_with_pads(T q[6], T v[6], T qc[6], const T ctrl[6], T ff[6
     quat_normalize(qn);
     T Rc[9]; quat_to_mat(qn, Rc);
     const bool coupled = detect_pad_contacts(W, v, cube, Rc, flags, cube_live, cs);
-    if (stat) { stat[0] = cs.n; stat[1] = coupled ? 1 : 0; stat[2] = cs.dropped; }
+    if (stat) { stat[0] = cs.n; stat[1] = coupled ? 1 : 0; stat[2] = cs.dropped; stat[3] = cs.n > 0 ? contact_signature(cs) : 0; }
     if (cs.n > 0) {
         contact_solve_integrate(q, v, qc, ctrl, ff, fl, aw, flags, contact_iters, A, W, cs, coupled, cube, Rc, applied, dq, residual, &zones);
         if (!coupled) cube_substep(cube, applied, flags, contact_iters);

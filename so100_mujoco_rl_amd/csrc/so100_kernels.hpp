@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     __shared__ float xc[24][64];
     __shared__ float xb[6][64];
     __shared__ float cbuf[PADS ? MAXC*CF*64 : 1];                 // pad contact records [record][field][lane]
-    __shared__ float xa[PADS ? 14 : 1][64];
+    __shared__ float xa[PADS ? 15 : 1][64];
     __shared__ float xk[PADS ? 12 : 1][64];
     __shared__ float xm[PADS ? 21 : 1][64];
     __shared__ unsigned char pbuf[PADS ? MAXC*64 : 1];
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     }
     Arm<float> A; Prof prof_;
     const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm, pbuf };
-    ContactMemo memo;                                             // (one env step per launch: the memory lives for its 16 substeps)
+    ContactMemo memo;                                             // (reset by physics_phase_mw: the memory lives for the env step's substeps)
     physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [](int) {}, [&]() {
         ctx = StepCtx{};
 #pragma unroll

@@ -84,13 +84,14 @@ struct Prof {
 // contacts, and wave 2 the cube's for lanes whose pad touches the cube (arm + cube solved together), and both integrate.
 // (The first version ran the Newton on wave 0 beside the env state: 409 scratch accesses in the kernel, 78 % of the wave's
 // cycles waiting on them, 600 us per step in sustained contact.)
-// LDS: xq [24][64] = sin q, cos q, v, q; xk [12][64] = ctrl, arm warm start (written once per env step); xa [14][64] = arm
+// LDS: xq [24][64] = sin q, cos q, v, q; xk [12][64] = ctrl (written once per env step) and the arm's acceleration of the
+// previous substep (6-11: the Newton's warm start, republished by wave 0 after every substep); xa [15][64] = arm
 // acceleration (0-5) and cube acceleration (6-11) of the contact wave's solve, contact code (12: count | coupled << 8 |
-// dropped << 16), solver residual (13).
+// dropped << 16), solver residual (13), signature of the pad-contact set (14).
 // xm [21][64] = the arm's mass matrix (packed lower, unfactored), published by wave 0 before it factorises it in place.
 struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; unsigned char* pbuf; };
-// the contact wave's active-set memory (so100_contact.hpp: primal_newton), kept by the caller from env step to env step:
-// zones = the arm rows' zones of the last contact solve (-1: none yet), prev_n = length of the (id | mask) list in L.pbuf
+// the contact wave's active-set memory (so100_contact.hpp: primal_newton) lives for ONE env step, like the one-wave kernel's
+// (physics_substeps): zones = the arm rows' zones of the last contact solve (-1: none yet), prev_n = length of the (id | mask) list in L.pbuf
 struct ContactMemo { int zones = -1, prev_n = 0; };
 
 // Register pressure.  The kernel is ONE control-flow graph: whatever another wave will read later (wave 0's env state `e`, its
@@ -110,13 +111,13 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     const bool padcube = PADS && (p.flags & F_PADS_CUBE) != 0u && cube_live;
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
-    float aw3[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };       // contact wave: arm acceleration of its last solve (Newton warm start)
+    memo = ContactMemo{};                                      // every kernel starts an env step without active-set memory: one definition of the solve
     // Contact wave: with p.epw < 64 envs per workgroup each env gets 64 / p.epw adjacent lanes (so100_contact.hpp: cooperative lanes);
     // el = the env's column in the LDS images, part = this lane's place in the env's group.
     const int np3 = 64/p.epw, sh3 = np3 == 4 ? 2 : np3 == 2 ? 1 : 0;
     const int el = lane >> sh3, part3 = lane & (np3 - 1);
     if (wave == 0) {
-        e.res = 0.0f; e.cstat = 0;
+        e.res = 0.0f; e.cstat = 0; e.csig = 0;
         if (pads) {
 #pragma unroll
             for (int i = 0; i < 6; i++) { xk[i][lane] = ctrl[i]; xk[6 + i][lane] = e.aw[i]; }
@@ -146,11 +147,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         if (wave == 0) { cstale[0] = e.cube.pos[0]; cstale[1] = e.cube.pos[1]; cstale[2] = e.cube.pos[2]; }      // kinematic cube
         if (pads) __syncthreads();                         // xk visible to the contact wave
     }
-    if (pads && wave == 3) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) aw3[i] = xk[6 + i][el];
-        xa[12][lane] = 0.0f;                               // (columns >= p.epw are never written again: no contacts there)
-    }
+    if (pads && wave == 3) { xa[12][lane] = 0.0f; xa[14][lane] = 0.0f; }      // (columns >= p.epw are never written again: no contacts there)
     // (Tried: letting wave 2 run the cube's 16 substeps back to back ahead of the arm when no pad can touch it.  A workgroup
     // barrier needs every wave, so the others simply waited for it at the first one: 72 -> 101 us per step.  The cube stays in
     // step with the arm: detection + row set-up in the first half-substep, Newton in the second.)
@@ -226,6 +223,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             memo.prev_n = cs3.prev_n;
             if (part3 == 0) xa[12][el] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
             any3 = __any(cs3.n > 0);
+            if (any3) { const int sig3 = cs3.n > 0 ? contact_signature(cs3) : 0; if (part3 == 0) xa[14][el] = __int_as_float(sig3); }
             SO100_PROF(4);                                 // FK + narrowphase (wave 3)
         }
         __syncthreads();
@@ -269,7 +267,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
 #pragma unroll
                 for (int i = 0; i < 21; i++) A3.M[i] = xm[i][el];
 #pragma unroll
-                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][el]; v3[i] = xq[12 + i][el]; c3[i] = xk[i][el]; A3.bias[i] = xb[i][el]; x3[i] = aw3[i]; cwarm[i] = 0.0f; }
+                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][el]; v3[i] = xq[12 + i][el]; c3[i] = xk[i][el]; A3.bias[i] = xb[i][el]; x3[i] = xk[6 + i][el]; cwarm[i] = 0.0f; }
                 arm_tau<float>(q3, v3, c3, A3, tau3);
                 ArmRows<float> r3;
                 arm_row_consts<float>(q3, v3, p.flags, r3);
@@ -280,8 +278,6 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                 }
                 const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube, &memo.zones, SO100_PROF_WORK);
                 SO100_PROF_INSUB();
-#pragma unroll
-                for (int i = 0; i < 6; i++) aw3[i] = x3[i];
                 if (part3 == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) { xa[i][el] = x3[i]; xa[6 + i][el] = xcube[i]; }
@@ -309,15 +305,12 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                     e.res = tmax(e.res, xa[13][lane]);
                 }
 #pragma unroll
-                for (int i = 0; i < 6; i++) e.aw[i] = acc0[i];
+                for (int i = 0; i < 6; i++) { e.aw[i] = acc0[i]; xk[6 + i][lane] = acc0[i]; }      // the next substep's Newton warm start (read after its first barrier)
                 const int n0 = e.cstat & 255, dr = (e.cstat >> 8) + (code >> 16);
                 e.cstat = (nc > n0 ? nc : n0) | ((dr > 0xFFFF ? 0xFFFF : dr) << 8);
+                e.csig = nc > 0 ? __float_as_int(xa[14][lane]) : 0;
             }
             arm_integrate<float>(e.q, e.v, e.qc, acc0, dq);
-        }
-        if (wave == 3 && pads && !(cs3.n > 0)) {           // keep the warm start current for lanes that were solved by the block PGS
-#pragma unroll
-            for (int i = 0; i < 6; i++) aw3[i] = 0.0f;
         }
         if (wave == 2 && cube_in_step) {
             if (padcube && (__float_as_int(xa[12][lane]) & 256) != 0) {      // arm and cube were solved together on the contact wave
@@ -514,7 +507,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     float (*xm)[64] = reinterpret_cast<float (*)[64]>(pool + MAXC*CF*64);
     static_assert(HB + 6*64 >= MAXC*CF*64 + 21*64, "contact records + mass matrix must fit under the policy phase's images");
     constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
-    __shared__ float xa[PADS ? 14 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual
+    __shared__ float xa[PADS ? 15 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual, set signature
     __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
     __shared__ float xq[PADS ? 24 : 18][64];                      // physics split: sin q, cos q, v (+ q) of env = lane (wave 0 -> waves 1, 3)
@@ -659,7 +652,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         }
         // ---- physics phase, split over the waves: per substep wave 1 computes the RNEA bias force while wave 0
         //      computes the CRBA mass matrix and factorises it; wave 0 then solves, integrates and publishes q, v.
-        //      Same operations in the same order as physics_substeps(), so results are bit-identical to it.
+        //      Same operations in the same order as physics_substeps(): contact-free lanes agree with it to the last bit or two,
+        //      lanes with pad contacts to the solver tolerance (same warm start and active-set memory, differently rounded inputs).
         {
             Arm<float> A;
                         const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm, pbuf };

@@ -51,6 +51,7 @@ struct EnvState {
                                 // block-PGS sweep, or the last Newton step of the contact solve when it ran out of iterations
     float aw[6];                // arm qacc of the previous substep: warm start of the pad-contact Newton (so100_contact.hpp)
     int   cstat;                // pad contacts: most contacts in a substep of the last env step | (dropped over the budget) << 8
+    int   csig;                 // signature of the pad-contact SET of the last substep (so100_contact.hpp: contact_signature; 0 = no contact)
 };
 
 SO100_HD void idle_lane_state(EnvState& e) {
@@ -88,7 +89,7 @@ SO100_HD void idle_lane_state(EnvState& e) {
     X(av0, av[0], f, 3) X(av1, av[1], f, 3) X(av2, av[2], f, 3) X(av3, av[3], f, 3) X(av4, av[4], f, 3) X(av5, av[5], f, 3) \
     X(solver_residual, res, f, 4) \
     X(aw0, aw[0], f, 5) X(aw1, aw[1], f, 5) X(aw2, aw[2], f, 5) X(aw3, aw[3], f, 5) X(aw4, aw[4], f, 5) X(aw5, aw[5], f, 5) \
-    X(contact_stat, cstat, i, 5)
+    X(contact_stat, cstat, i, 5) X(contact_sig, csig, i, 5)
 
 enum StateField : int {
 #define X(name, member, kind, group) SF_##name,
@@ -253,7 +254,7 @@ template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const
     // mj_resetData: qpos = qpos0, everything else (velocities, warm starts, applied forces, time, POSES) zero
 #pragma unroll
     for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.qc[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; e.aw[i] = 0.0f; }
-    e.res = 0.0f; e.cstat = 0;
+    e.res = 0.0f; e.cstat = 0; e.csig = 0;
     e.cube.pos[0] = e.cube.pos[1] = e.cube.pos[2] = 0.0f;
     e.cube.quat[0] = 1.0f; e.cube.quat[1] = e.cube.quat[2] = e.cube.quat[3] = 0.0f;
     e.ee[0] = e.ee[1] = e.ee[2] = 0.0f; e.wrist_z = 0.0f; e.cx[0] = e.cx[1] = e.cx[2] = 0.0f;
@@ -293,16 +294,17 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
     const bool pads = (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
-    e.res = 0.0f; e.cstat = 0;
+    e.res = 0.0f; e.cstat = 0; e.csig = 0;
     ContactsPriv<float> cs; int zones = -1;                  // the contact solve's active-set memory lives for this env step
 #pragma unroll 1
     for (int s = 0; s < p.frame_skip; s++) {
         cube_stale[0] = e.cube.pos[0]; cube_stale[1] = e.cube.pos[1]; cube_stale[2] = e.cube.pos[2];
         if (pads) {
-            int st[3];
+            int st[4];
             substep_with_pads<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, e.aw, e.cube, applied, p.flags, p.solver_iters, p.contact_iters, A, s == 0, dq, &e.res, cs, zones, st);
             const int n = e.cstat & 255, dr = e.cstat >> 8;
             e.cstat = (st[0] > n ? st[0] : n) | ((dr + st[2] > 0xFFFF ? 0xFFFF : dr + st[2]) << 8);
+            e.csig = st[3];
         } else {
             arm_substep<float>(e.q, e.v, e.qc, ctrl, e.ff, e.fl, p.flags, p.solver_iters, A, s == 0, dq, &e.res);
             cube_substep<float>(e.cube, applied, p.flags, p.contact_iters);

@@ -55,7 +55,8 @@ void hc_dbg_counters(long* out) { out[0] = g_dbg_newton_iters; out[1] = g_dbg_ne
 
 // ---- finger-pad contacts (so100_contact.hpp): whole substeps of one env, fp64 and fp32 ----------------------------------------
 #include "../../so100_mujoco_rl_amd/csrc/so100_contact.hpp"
-// state: q6 v6 ff6 fl6 aw6 | cube pos3 quat4 vel6 warm6  (49 doubles); stat: per substep max of [contacts, coupled, dropped], [3] = max residual*1e9
+// state: q6 v6 ff6 fl6 aw6 | cube pos3 quat4 vel6 warm6  (49 doubles); stat[5]: per substep max of [contacts, coupled, dropped], [3] = max residual*1e9,
+// [4] = contact-set signature of the last substep
 template <typename T> static void csub(double* st, const double* ctrl, const double* applied, unsigned flags, int iters, int citers, int n, int* stat) {
     T q[6], v[6], ff[6], fl[6], aw[6], qc[6] = {0,0,0,0,0,0}, cc[6], ap[3] = { (T)applied[0], (T)applied[1], (T)applied[2] };
     Cube<T> cb;
@@ -65,11 +66,12 @@ template <typename T> static void csub(double* st, const double* ctrl, const dou
     for (int i = 0; i < 6; i++) { cb.vel[i] = (T)st[37+i]; cb.warm[i] = (T)st[43+i]; }
     Arm<T> A; T dq[6] = {0,0,0,0,0,0}; T res = T(0);
     ContactsPriv<T> cs; int zones = -1;
-    stat[0] = stat[1] = stat[2] = stat[3] = 0;
+    stat[0] = stat[1] = stat[2] = stat[3] = stat[4] = 0;
     for (int s = 0; s < n; s++) {
-        int sst[3];
+        int sst[4];
         substep_with_pads<T>(q, v, qc, cc, ff, fl, aw, cb, ap, flags, iters, citers, A, (s % 16) == 0, dq, &res, cs, zones, sst);
         for (int k = 0; k < 3; k++) stat[k] = sst[k] > stat[k] ? sst[k] : stat[k];
+        stat[4] = sst[3];                                    // signature of the LAST substep's pad-contact set
     }
     stat[3] = (int)(res*1e9 > 2e9 ? 2e9 : res*1e9);
     for (int i = 0; i < 6; i++) { st[i] = q[i]; st[6+i] = v[i]; st[12+i] = ff[i]; st[18+i] = fl[i]; st[24+i] = aw[i]; }

@@ -203,7 +203,8 @@ def test_contact_kernels_agree_with_each_other(flags):
         qpos, qvel, act = _grasp_batch(m, 2)
     else:
         qpos, qvel, act = _floor_batch(m, 2)
-    outs = {}
+        act[:] = act[0]; act[:, 1] = 0.6                     # ONE action for the whole batch (shoulder down), so that the persistent kernel's
+    outs = {}                                                # bias-only policy below can reproduce it: its rollout leg runs for both flag sets
     for name, n in (("mw", m), ("fused", 16384 + m)):
         sim = _sim(1, n, flags=flags, contact_iters=12, max_episode_steps=0, seed=3)
         QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.2, 0.0099]; QP[:, :6] = [0, -1.5, 1.5, 0.5, 0, 0.2]; QV = np.zeros((n, 12))
@@ -219,17 +220,18 @@ def test_contact_kernels_agree_with_each_other(flags):
     sd["action_net.weight"].zero_(); sd["action_net.bias"].copy_(torch.from_numpy(act[0])); sd["log_std"].fill_(-30.0)
     col = RolloutCollector(env, sd, T=3, persistent=True, bootstrap_truncated=False)
     _inject(env.sim, qpos, qvel); col._started = True
-    assert np.abs(act - act[0]).max() < 1.5 or True
-    if np.abs(act - act[0]).max() == 0:                      # grasp batch: one action for all envs -> the rollout kernel can be compared too
-        col.collect(3)
-        q, v = env.sim.get_state()
-        outs["rollout"] = (q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone())
+    assert np.abs(act - act[0]).max() == 0                   # one action for all envs -> the rollout kernel is compared too
+    col.collect(3)
+    q, v = env.sim.get_state()
+    outs["rollout"] = (q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone())
+    assert set(outs) == {"mw", "fused", "rollout"}
     ref = outs["mw"]
     assert (ref[2] & 255).max() >= 2
     for name, o in outs.items():
         if name == "mw":
             continue
         same = (o[2] & 255) == (ref[2] & 255)
+        print(f"[kernels agree, flags {flags}] {name} vs mw: same contact count in {float(same.float().mean()):.3f} of {m} envs")
         assert same.float().mean() > 0.9, name
         dq = (o[0] - ref[0]).abs().amax(0); dv = (o[1] - ref[1]).abs().amax(0)
         # the kernels differ in their Newton warm starts (the contact wave of the multi-wave kernels starts a lane's first contact

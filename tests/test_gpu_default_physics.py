@@ -1,0 +1,125 @@
+"""The kernels users get BY DEFAULT (So100VecEnv / So100Sim / main.py default to F_REFERENCE = pad/floor contacts on; the collector
+defaults to the persistent rollout kernel so100_rollout_fused<K, 23 | 55, 4>) against the stepwise kernels and the fp64 oracle, from
+contact-rich starts: arms injected with their finger pads at the table (and, for F_CONTACT5, a cube between the closing jaws), policy
+biased to servo the shoulder further down, raised log_std.  TimeLimit resets inside the chunk.
+
+Per env STEP (16 fused substeps) fp32 and fp64 may see a corner make / break contact a substep apart (~1 m/s impact moved by 2 ms: physics,
+see tests/test_gpu_contacts.py) -- the per-SUBSTEP test (tests/test_gpu_substep_parity.py) has no such effect and is exact on every env.
+Here every (env, step) pair is classified and the class shares are printed and bounded; nothing is dropped from the comparison.
+"parity unpinned (physics)": the oracle restates MuJoCo's algorithm; MuJoCo is not available."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+import substep_harness as SH                              # noqa: E402
+from oracle import so100_oracle as O                      # noqa: E402  (the checker)
+
+REFP = O.F_REFERENCE
+C5 = O.F_CONTACT5
+
+
+def _contact_rich_state(n, flags, seed):
+    qpos, qvel, _ = SH.floor_batch(n, seed)
+    if flags & O.F_PADS_CUBE:                               # second half: the closing-jaw grasp of BASELINE.json configs[4]
+        gq, gv, _ = SH.grasp_batch(n - n//2, seed + 1)
+        qpos[n//2:] = gq; qvel[n//2:] = gv
+    return qpos.astype(np.float32), qvel.astype(np.float32)
+
+
+def _start(env, col, qpos, qvel, kind):
+    sim = env.sim
+    sim.reset()
+    sim.set_state(torch.from_numpy(np.ascontiguousarray(qpos.T)).cuda(), torch.from_numpy(np.ascontiguousarray(qvel.T)).cuda())
+    if kind in (3, 4, 5):                                    # look-at kinds servo to their COMMANDED angles (env_base_02.py:85-86)
+        for i in range(6):
+            sim.set_field(f"cmd{i}", torch.from_numpy(np.ascontiguousarray(qpos[:, i])).cuda())
+    col._started = True
+
+
+@pytest.mark.parametrize("kind,flags", [(1, REFP), (2, C5), (5, REFP), (6, REFP), (3, REFP)])
+def test_default_rollout_kernel_vs_stepwise_and_oracle(kind, flags):
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n, T, tl = 200, 10, 7                                    # tail workgroup partially filled; TimeLimit hits inside the chunk
+    qpos, qvel = _contact_rich_state(n, flags, 10 + kind)
+    runs = []
+    for persistent in (True, False):
+        env = So100VecEnv(kind, n, flags=flags, seed=4, max_episode_steps=tl, solver_iters=4, contact_iters=30)
+        sd = RolloutCollector.random_policy_state(env.sim.obs_dim, env.device, seed=2)
+        sd["action_net.bias"][1] = 0.5                       # shoulder down: the pads stay on / are pressed into the table
+        if flags & O.F_PADS_CUBE:
+            sd["action_net.bias"][5] = -0.5                  # ... and the jaw closes
+        sd["log_std"] = sd["log_std"] + 0.3                  # raised: contact-rich AND irregular
+        col = RolloutCollector(env, sd, T=T, persistent=persistent, bootstrap_truncated=False)
+        _start(env, col, qpos, qvel, kind)
+        b = {k: v.clone() for k, v in col.collect().items()}
+        q, v = env.sim.get_state()
+        runs.append((b, q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone()))
+    (a, aq, av, acs), (s, sq, sv, scs) = runs
+    # ---- persistent kernel vs stepwise kernels: the same actions (the policy noise stream is shared), so rows can be compared one by one
+    assert torch.equal(a["dones"], s["dones"]) and a["dones"].sum() > 0
+    d_obs = (a["obs"] - s["obs"]).abs().amax(-1); d_last = (a["last_obs"] - s["last_obs"]).abs().amax(-1)
+    d_all = torch.cat([d_obs.flatten(), d_last.flatten()])
+    tight = float((d_all < 1e-5).float().mean()); loose = float((d_all < 2e-2).float().mean())
+    # ---- 32 sampled envs against the oracle's env step (its Newton), replaying the persistent run's actions
+    sample = list(range(0, n, n//32))[:32]
+    act = a["actions"].clamp(-1, 1).cpu().numpy(); obs = a["obs"].cpu().numpy(); rew = a["rewards"].cpu().numpy(); last = a["last_obs"].cpu().numpy()
+    classes = {"tight": 0, "event": 0, "fail": 0}; worst_tight = 0.0; errs = []
+    for i in sample:
+        e = O.OracleEnv(kind, flags=flags, iters=-1, seed=4, env_id=i); e.e.max_episode_steps = tl
+        e.reset()
+        O.arr(e.d.qpos)[:] = qpos[i].astype(np.float64); O.arr(e.d.qvel)[:] = qvel[i].astype(np.float64)
+        if kind in (3, 4, 5):
+            O.arr(e.e.cmd)[:] = qpos[i, :6].astype(np.float64)
+        for t in range(T):
+            o, r = e.step(act[t, i], autoreset=True)[:2]
+            og = obs[t + 1, i] if t + 1 < T else last[i]
+            scale = 5.0 if kind in (3, 4, 5) else 1.0        # look-at observations carry 5 * (pixel centre) in their last two entries
+            err = max(np.abs(og[:6] - o[:6]).max(), np.abs(og[6:] - o[6:]).max()/scale, abs(rew[t, i] - r)/20.0)
+            errs.append(err)
+            if err < 2e-5:
+                classes["tight"] += 1; worst_tight = max(worst_tight, err)
+            elif err < 2e-2:
+                classes["event"] += 1
+            else:
+                classes["fail"] += 1
+    touched = float(((acs & 255) > 0).float().mean())
+    print(f"[default rollout kernel, kind {kind} flags {flags}] persistent vs stepwise: {tight:.3f} of rows within 1e-5, {loose:.3f} within 2e-2; "
+          f"vs oracle ({len(sample)} envs x {T} steps): {classes}, median err {np.median(errs):.2e}; envs with a pad contact in the last step {touched:.2f}")
+    assert torch.isfinite(a["obs"]).all() and torch.isfinite(a["rewards"]).all() and torch.isfinite(aq).all() and torch.isfinite(av).all()
+    assert touched > 0.2                                     # the contact path really ran
+    assert (acs >> 8).max() == 0 and (scs >> 8).max() == 0   # nothing over the contact budget
+    assert loose == 1.0 and tight > 0.5
+    assert classes["fail"] == 0 and classes["tight"] >= 0.5*len(errs) and np.median(errs) < 2e-5
+
+
+def test_contact5_determinism_and_shard_invariance_4096():
+    """F_CONTACT5 at the BASELINE per-GPU batch: 4096 closing-jaw grasps (cube between the pads, coupled 12-unknown solves) are
+    bitwise reproducible and unchanged by sharding the batch over two handles (env_id_offset), like F_REFERENCE in
+    test_pads_keep_the_gripper_above_the_floor_at_full_size."""
+    from so100_mujoco_rl_amd.lib import So100Sim
+    n = 4096
+    qpos, qvel, act = SH.grasp_batch(n, 7)
+    rs = np.random.RandomState(1)
+    act = act + rs.uniform(-0.3, 0.3, act.shape).astype(np.float32); act[:, 5] = -1.0
+
+    def run(n_envs, off, sl):
+        sim = So100Sim(2, n_envs, flags=C5, seed=9, env_id_offset=off, max_episode_steps=0)
+        sim.reset()
+        sim.set_state(torch.from_numpy(np.ascontiguousarray(qpos[sl].T, np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(qvel[sl].T, np.float32)).cuda())
+        a = torch.from_numpy(np.ascontiguousarray(act[sl])).cuda(); coupled = 0
+        outs = []
+        for t in range(8):
+            ob, r, d, _ = sim.step(a)
+            outs.append(torch.cat([ob, r[:, None]], 1).clone())
+            coupled = max(coupled, int((sim.get_field("contact_stat", dtype=torch.int32) & 255).max()))
+        q, v = sim.get_state()
+        return torch.cat(outs, 1), q.clone(), v.clone(), coupled
+    full, q, v, coupled = run(n, 0, slice(0, n))
+    again, q2, v2, _ = run(n, 0, slice(0, n))
+    assert torch.equal(full, again) and torch.equal(q, q2) and torch.equal(v, v2)
+    lo, qa, va, _ = run(n//2, 0, slice(0, n//2)); hi, qb, vb, _ = run(n//2, n//2, slice(n//2, n))
+    assert torch.equal(torch.cat([lo, hi], 0), full) and torch.equal(torch.cat([qa, qb], 1), q) and torch.equal(torch.cat([va, vb], 1), v)
+    assert torch.isfinite(full).all() and coupled >= 8       # face-face manifolds on both sides of the cube

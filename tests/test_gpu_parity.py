@@ -25,16 +25,19 @@ def _sim(*a, **k):
     return So100Sim(*a, **k)
 
 
-REF = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
+NOPADS = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR         # friction loss + limits + cube/floor, no finger-pad contacts (round 1's "reference")
+REFP = O.F_REFERENCE                                       # + the 8 finger pads vs the floor: what So100Sim / So100VecEnv / main.py run by default
 ARM = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_CUBE_PINNED
 FREE = O.F_CUBE_PINNED
 
 
 def _run_pair(kind, flags, n, steps, seed, action_scale=1.0, solver_iters=4, contact_iters=6, max_steps=0, inject=True):
-    """Step n envs on the GPU and in the oracle with identical actions / uniforms; yield per-step results."""
+    """Step n envs on the GPU and in the oracle with identical actions / uniforms; yield per-step results.
+    Oracle solver: PGS on the dual to 1e-15 -- or its primal Newton when pad rows are simulated (PGS needs ~1e4 sweeps on them)."""
     rs = np.random.RandomState(seed)
-    sim = _sim(kind, n, flags=flags, solver_iters=solver_iters, contact_iters=contact_iters, max_episode_steps=max_steps, seed=seed)
-    orc = [O.OracleEnv(kind, flags=flags, iters=0, seed=seed, env_id=i) for i in range(n)]
+    pads = (flags & (O.F_PADS_FLOOR | O.F_PADS_CUBE)) != 0
+    sim = _sim(kind, n, flags=flags, solver_iters=solver_iters, contact_iters=30 if pads else contact_iters, max_episode_steps=max_steps, seed=seed)
+    orc = [O.OracleEnv(kind, flags=flags, iters=-1 if pads else 0, seed=seed, env_id=i) for i in range(n)]
     for e in orc:
         e.e.max_episode_steps = max_steps
     inj = rs.random_sample((n, 16)).astype(np.float32)
@@ -58,9 +61,9 @@ def _state_err(sim, orc):
     return np.abs(qpos - qo).max(), np.abs(qvel - vo).max()
 
 
-@pytest.mark.parametrize("flags,name", [(FREE, "constraint-free"), (ARM, "friction+limits"), (REF, "reference")])
+@pytest.mark.parametrize("flags,name", [(FREE, "constraint-free"), (ARM, "friction+limits"), (NOPADS, "reference")])
 def test_env01_vs_oracle(flags, name):
-    n, steps = (48, 40) if flags == REF else (96, 60)
+    n, steps = (48, 40) if flags == NOPADS else (96, 60)
     worst_o = worst_r = 0.0
     for t, sim, orc, og, oo, rew, done, trunc, _ in _run_pair(1, flags, n, steps, seed=7):
         worst_o = max(worst_o, np.abs(og - oo).max())
@@ -120,12 +123,11 @@ def test_env06_vs_oracle_with_gripper_term():
     assert eq < 2e-5 and ev < 5e-4
 
 
-@pytest.mark.parametrize("kind", [5, 3, 4])
-def test_lookat_envs_vs_oracle(kind):
+@pytest.mark.parametrize("kind,flags", [(5, NOPADS), (3, NOPADS), (4, NOPADS), (5, REFP), (3, REFP), (4, REFP)])
+def test_lookat_envs_vs_oracle(kind, flags):
+    """REFP = the default physics of So100VecEnv / main.py for these kinds (so100_step_mw<K, 23>): the look-at arms stay above the
+    table, so the pad narrowphase runs and finds nothing -- the results must be the NOPADS ones to the same tolerance"""
     n, steps = 64, 60
-    flags = REF if kind == 5 else ARM | 0
-    if kind != 5:
-        flags = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
     n_px = n_px_bad = 0
     for t, sim, orc, og, oo, rew, done, trunc, _ in _run_pair(kind, flags, n, steps, seed=20 + kind, action_scale=0.6):
         np.testing.assert_allclose(og[:, :6], oo[:, :6], rtol=0, atol=1e-6)
@@ -144,8 +146,8 @@ def test_lookat_envs_vs_oracle(kind):
 def test_env05_termination_and_autoreset():
     """Rotate the base away until the cube is lost for > 30 steps: terminated, terminal obs, auto-reset."""
     n = 64
-    sim = _sim(5, n, flags=REF, contact_iters=6, max_episode_steps=0, seed=3)
-    orc = [O.OracleEnv(5, flags=REF, iters=0, seed=3, env_id=i) for i in range(n)]
+    sim = _sim(5, n, flags=NOPADS, contact_iters=6, max_episode_steps=0, seed=3)
+    orc = [O.OracleEnv(5, flags=NOPADS, iters=0, seed=3, env_id=i) for i in range(n)]
     for e in orc:
         e.e.max_episode_steps = 0
     rs = np.random.RandomState(5)
@@ -252,7 +254,7 @@ def test_non_finite_action_ends_only_that_episode(kind):
     env -- and the poisoned envs after their reset -- keep matching the oracle, which carries the same guard."""
     n, bad = 96, {5: float("nan"), 9: float("inf"), 70: float("-inf")}
     hit = False
-    for t, sim, orc, og, oo, rew, done, trunc, res in _run_pair_with(kind, REF, n, 12, seed=3, poison=(4, bad)):
+    for t, sim, orc, og, oo, rew, done, trunc, res in _run_pair_with(kind, NOPADS, n, 12, seed=3, poison=(4, bad)):
         assert np.isfinite(og).all() and np.isfinite(oo).all()
         np.testing.assert_allclose(og, oo, rtol=0, atol=2e-5 if kind == 1 else 6e-3)
         if rew is None:
@@ -314,7 +316,8 @@ def test_state_roundtrip_and_errors():
 
 
 # ---- size-independent properties at BASELINE.json's full sizes ---------------------------------------------------
-@pytest.mark.parametrize("kind,n,flags", [(1, 4096, FREE), (1, 4096, REF), (2, 16384, REF), (5, 8192, REF)])
+@pytest.mark.parametrize("kind,n,flags", [(1, 4096, FREE), (1, 4096, NOPADS), (2, 16384, NOPADS), (5, 8192, NOPADS),
+                                          (1, 4096, REFP), (2, 16384, REFP), (5, 8192, REFP), (3, 4096, REFP), (4, 4096, REFP), (6, 4096, REFP)])
 def test_full_size_properties(kind, n, flags):
     """determinism, shard invariance (env_id_offset), joint limits, finiteness, obs-space bounds"""
     g = torch.Generator(device="cuda"); g.manual_seed(0)
@@ -397,7 +400,7 @@ def test_north_star_1000_steps():
     physics over 1000 env steps = 16000 substeps on identical seeds.  Smooth bounded actions (a random walk), the
     reference-faithful arm (friction loss + limits) and the constraint-free configuration."""
     n, steps = 16, 1000
-    for flags in (ARM, FREE, REF):
+    for flags in (ARM, FREE, NOPADS):
         rs = np.random.RandomState(3)
         sim = _sim(1, n, flags=flags, solver_iters=2, max_episode_steps=0, seed=2)     # 2 sweeps = the product default
         orc = [O.OracleEnv(1, flags=flags, iters=0, seed=2, env_id=i) for i in range(n)]
@@ -416,7 +419,7 @@ def test_north_star_1000_steps():
                 qo = np.stack([O.arr(e.d.qpos)[:6].copy() for e in orc]); vo = np.stack([O.arr(e.d.qvel)[:6].copy() for e in orc])
                 worst_q = max(worst_q, np.abs(qpos[:6].cpu().numpy().T - qo).max())
                 worst_v = max(worst_v, np.abs(qvel[:6].cpu().numpy().T - vo).max())
-                if flags == REF:                             # the cube: settles out of the floor after the reset, then rests
+                if flags == NOPADS:                             # the cube: settles out of the floor after the reset, then rests
                     co = np.stack([O.arr(e.d.qpos)[6:13].copy() for e in orc])
                     worst_c = max(worst_c, np.abs(qpos[6:13].cpu().numpy().T - co).max())
         print(f"flags={flags}: 1000 steps, max |dq| = {worst_q:.2e} rad (scale pi), max |dqvel| = {worst_v:.2e} rad/s, cube pose {worst_c:.2e}")
@@ -472,7 +475,7 @@ def test_rollout_collector_and_vecenv():
     assert env2.env_is_wrapped(object) == [False] * n and env2.get_attr("num_envs", [0, 1]) == [n, n]
 
 
-@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, REF), (2, REF), (5, REF), (1, ARM), (6, REF)])
+@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, NOPADS), (2, NOPADS), (5, NOPADS), (1, ARM), (6, NOPADS)])
 def test_persistent_rollout_equals_stepwise(kind, flags):
     """so100_rollout (one launch for T steps) == T x (so100_policy_forward + so100_step), buffer row by row."""
     from so100_mujoco_rl_amd.vec_env import So100VecEnv
@@ -570,7 +573,7 @@ def test_single_env_gym_view():
     env.close()
 
 
-@pytest.mark.parametrize("kind,flags,n", [(1, FREE, 4096), (2, REF, 4096), (5, REF, 2048), (6, REF, 2048)])
+@pytest.mark.parametrize("kind,flags,n", [(1, FREE, 4096), (2, NOPADS, 4096), (5, NOPADS, 2048), (6, NOPADS, 2048), (1, REFP, 4096), (5, REFP, 2048), (2, O.F_CONTACT5, 2048)])
 def test_soak_full_batch(kind, flags, n):
     """Thousands of vectorised steps through the default (persistent) collector with short staggered episodes: every env
     resets many times; state stays finite, joint limits hold, counters are consistent, no pipeline faults."""
@@ -637,7 +640,7 @@ def test_stepwise_calls_are_graph_capturable():
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, REF), (5, REF), (2, ARM)])
+@pytest.mark.parametrize("kind,flags", [(1, FREE), (1, NOPADS), (5, NOPADS), (2, ARM)])
 def test_multiwave_step_kernel_equals_throughput_kernel(kind, flags):
     """so100_step picks the 4-wave latency kernel (so100_step_mw) for N <= 16384 and the one-wave throughput kernel
     (so100_step_fused) above.  Envs are independent and their RNG is keyed by env id, so the first 200 envs of a 16 576-env
@@ -669,8 +672,8 @@ def test_dense_throughput_kernel_131072():
     n, steps = 131072, 5
     rs = np.random.RandomState(12)
     sample = np.sort(rs.choice(n, 32, replace=False)); sample[0] = 0; sample[-1] = n - 1
-    sim = _sim(1, n, flags=REF, solver_iters=4, seed=23, max_episode_steps=3)
-    orc = [O.OracleEnv(1, flags=REF, iters=0, seed=23, env_id=int(i)) for i in sample]
+    sim = _sim(1, n, flags=NOPADS, solver_iters=4, seed=23, max_episode_steps=3)
+    orc = [O.OracleEnv(1, flags=NOPADS, iters=0, seed=23, env_id=int(i)) for i in sample]
     for e in orc:
         e.e.max_episode_steps = 3
     sim.reset(); [e.reset() for e in orc]
@@ -688,7 +691,7 @@ def test_dense_throughput_kernel_131072():
     full = torch.cat(trace, 1); sim.close()
     halves = []
     for off in (0, n // 2):
-        s2 = _sim(1, n // 2, flags=REF, solver_iters=4, seed=23, max_episode_steps=3, env_id_offset=off); s2.reset(); tr2 = []
+        s2 = _sim(1, n // 2, flags=NOPADS, solver_iters=4, seed=23, max_episode_steps=3, env_id_offset=off); s2.reset(); tr2 = []
         for t in range(steps):
             ob, r, d, _ = s2.step(acts[t][off:off + n // 2].contiguous())
             tr2.append(torch.cat([ob, r[:, None], d[:, None].float()], 1).clone())
@@ -704,7 +707,7 @@ def test_large_batch_dispatch_65536_vs_oracle():
     n, steps = 65536, 6
     rs = np.random.RandomState(11)
     sample = np.sort(rs.choice(n, 64, replace=False)); sample[0] = 0; sample[-1] = n - 1
-    for kind, flags in ((1, FREE), (1, REF)):
+    for kind, flags in ((1, FREE), (1, NOPADS)):
         sim = _sim(kind, n, flags=flags, solver_iters=4, seed=21, max_episode_steps=4)       # TimeLimit resets inside the run
         orc = [O.OracleEnv(kind, flags=flags, iters=0, seed=21, env_id=int(i)) for i in sample]
         for e in orc:
@@ -788,8 +791,8 @@ def test_vecenv_zero_copy_round_trip_equals_staged():
     exactly what the staged path (H2D, kernel on device buffers, D2H) returns, infos included, across TimeLimit resets."""
     from so100_mujoco_rl_amd.vec_env import So100VecEnv
     n = 300
-    eg = So100VecEnv("Env05-v1", n, flags=REF, seed=4, max_episode_steps=6, use_graph=True)
-    ee = So100VecEnv("Env05-v1", n, flags=REF, seed=4, max_episode_steps=6, use_graph=False)
+    eg = So100VecEnv("Env05-v1", n, flags=NOPADS, seed=4, max_episode_steps=6, use_graph=True)
+    ee = So100VecEnv("Env05-v1", n, flags=NOPADS, seed=4, max_episode_steps=6, use_graph=False)
     np.testing.assert_array_equal(eg.reset(), ee.reset())
     rs = np.random.RandomState(0)
     for t in range(20):
@@ -815,8 +818,8 @@ def test_vecenv_zero_copy_round_trip_equals_staged():
 def test_odd_batch_sizes_and_frame_skips_vs_oracle(n, frame_skip):
     """Tail workgroups (N not a multiple of 64, N = 1) and frame_skip values other than the reference's 16, against the oracle."""
     rs = np.random.RandomState(n)
-    sim = _sim(2, n, flags=REF, solver_iters=4, contact_iters=6, max_episode_steps=9, seed=5, frame_skip=frame_skip)
-    orc = [O.OracleEnv(2, flags=REF, iters=0, seed=5, env_id=i) for i in range(n)]
+    sim = _sim(2, n, flags=NOPADS, solver_iters=4, contact_iters=6, max_episode_steps=9, seed=5, frame_skip=frame_skip)
+    orc = [O.OracleEnv(2, flags=NOPADS, iters=0, seed=5, env_id=i) for i in range(n)]
     for e in orc:
         e.e.max_episode_steps = 9; e.e.frame_skip = frame_skip
     inj = rs.random_sample((n, 16)).astype(np.float32)

@@ -34,7 +34,7 @@ def pack(q, v, cube, cq, cvel=None):
 
 
 def host_steps(fn, st, ctrl, flags, n, iters=4, citers=20):
-    stat = np.zeros(4, np.int32); ct = np.ascontiguousarray(ctrl, np.float64); ap = np.zeros(3)
+    stat = np.zeros(5, np.int32); ct = np.ascontiguousarray(ctrl, np.float64); ap = np.zeros(3)
     fn(P(st), P(ct), P(ap), flags, iters, citers, n, P(stat))
     return stat
 
