@@ -13,7 +13,7 @@ done code 2 in the rollout row; see rollout.bootstrap_truncated); `batch["last_v
 import torch
 
 from .lib import POLICY_TENSORS, SB3_STATE_DICT_KEYS
-from .rollout import RolloutChunk, bootstrap_truncated, gather_rollout
+from .rollout import RolloutChunk, bootstrap_truncated, gather_rollout, mean_over_ranks
 
 
 class RolloutCollector:
@@ -99,11 +99,15 @@ class RolloutCollector:
                 self.sim.step(self.act, rollout_row=row, terminal_obs=None if self.tobs is None else self.tobs[t])
                 self.counter += 1
         buf = self.chunk.buf[:T]
+        o = self.sim.obs_dim
+        # statistics are taken from the ENV's rewards, before the bootstrap adds the critic's gamma * V(terminal_observation) to the
+        # truncated steps: model selection / early stopping / the "reward/step" log line must not depend on the value estimates
+        raw_mean = buf[..., o + 6].mean()
         if self.bootstrap:
-            o = self.sim.obs_dim
             bootstrap_truncated(buf[..., o + 6], buf[..., o + 7], self.tobs[:T], self._value, self.gamma)
         last_obs = self.sim.obs
         if gather_dst is not None:
+            raw_mean = mean_over_ranks(raw_mean)
             buf = gather_rollout(buf.contiguous(), dst=gather_dst)
             last_obs = gather_rollout(last_obs.unsqueeze(0).contiguous(), dst=gather_dst)      # [1, N_total, obs_dim] on the learner rank
             if buf is None:
@@ -111,4 +115,5 @@ class RolloutCollector:
             last_obs = last_obs[0]
         out = self.chunk.unpack(buf)
         out["last_obs"] = last_obs
+        out["raw_reward_mean"] = raw_mean                    # 0-d tensor: mean env reward per step of this chunk (all ranks), bootstrap excluded
         return out

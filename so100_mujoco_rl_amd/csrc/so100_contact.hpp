@@ -30,6 +30,12 @@
 #if !defined(__HIPCC__)
 #include <cstdio>
 #endif
+#ifndef SO100_LEAN_DX
+#define SO100_LEAN_DX 0.02     // size of a Newton step, SO100_LEAN_ABS + SO100_LEAN_DX |x| (rad/s^2), up to which its round-off is removed by
+#endif                         // refining the LINEAR system (see primal_newton: lean_refine)
+#ifndef SO100_LEAN_ABS
+#define SO100_LEAN_ABS 2.0
+#endif
 
 namespace so100 {
 
@@ -604,10 +610,11 @@ template <int ND, typename T, class Store> struct PrimalProblem {
     int* zones;                // active-set memory of the arm's own rows: per joint 3 bits (friction 0 quadratic / 1 low / 2 high, limit active)
     static constexpr int NH = ND*(ND + 1)/2;
 
-    // MODE 1: gradient at x, 2: + Hessian.  (The cost VALUE is never formed: no step of the solver compares costs, see primal_newton.)
+    // MODE 0: only the active set x selects (recorded, compared with the remembered one: `same`); 1: gradient at x, 2: + Hessian.
+    // (The cost VALUE is never formed: no step of the solver compares costs, see primal_newton.)
     // FORCED: gradient and Hessian of the QUADRATIC whose active set is the remembered one (*zones, the records' mask0) instead of
     // the one x selects: its minimiser is the solution whenever the active set did not change since the previous substep.
-    // A plain MODE 2 pass records the active set it saw (*zones, the records' mask, the store's previous list) and reports in
+    // A plain MODE 2 (or MODE 0) pass records the active set it saw (*zones, the records' mask, the store's previous list) and reports in
     // `same` whether that is the set of the quadratic that produced x (the remembered one): if it is, and x is that quadratic's
     // minimiser (a full Newton step), x minimises the true cost -- the piecewise-quadratic problem's exact convergence test.
     template <int MODE, bool FORCED = false> SO100_HD void eval(const T x[ND], T g[ND], T H[NH], bool* same = nullptr) const {
@@ -646,7 +653,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 m_[e] = act[e] ? jar[e] : T(0);
                 mask |= act[e] ? 1 << e : 0;
             }
-            if (MODE == 2 && !FORCED) {
+            if ((MODE == 2 || MODE == 0) && !FORCED) {
                 differ |= mask ^ ((code >> 11) & 15);
                 cs.set(s, C_KIND, T((code & 2047) | (mask << 11)));
                 cs.setp(s, (contact_id_hash((code >> 3) & 255) << 4) | mask);
@@ -708,9 +715,11 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         // ---- the shares of the group's lanes meet (a group of one: nothing happens)
         if constexpr (Store::COOP) {
             if (cs.nparts > 1) {
+                if (MODE >= 1) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { F45[k] = coop_sum(cs, F45[k]); T45[k] = coop_sum(cs, T45[k]); F5[k] = coop_sum(cs, F5[k]); T5[k] = coop_sum(cs, T5[k]); }
-                if (ND == 12) {
+                    for (int k = 0; k < 3; k++) { F45[k] = coop_sum(cs, F45[k]); T45[k] = coop_sum(cs, T45[k]); F5[k] = coop_sum(cs, F5[k]); T5[k] = coop_sum(cs, T5[k]); }
+                }
+                if (ND == 12 && MODE >= 1) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) gc[k] = coop_sum(cs, gc[k]);
                 }
@@ -722,19 +731,21 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             }
         }
         // ---- smooth part, arm: 1/2 x'Mx - x'tau (+ the cube's), then the contact wrenches -> joint space: g_i += z_i . (T - o_i x F), links >= i
+        if (MODE >= 1) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            T t = T(0);
+            for (int i = 0; i < 6; i++) {
+                T t = T(0);
 #pragma unroll
-            for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
-            const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;        // z . (T - o x F) = z . T + (o x z) . F
-            g[i] = (t - tau[i]) + (dot(W.z[i], Ta) + dot(W.oz[i], Fa));
+                for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
+                const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;    // z . (T - o x F) = z . T + (o x z) . F
+                g[i] = (t - tau[i]) + (dot(W.z[i], Ta) + dot(W.oz[i], Fa));
+            }
         }
         if (MODE == 2) {
 #pragma unroll
             for (int i = 0; i < 21; i++) H[i] += Marm[i];
         }
-        if (ND == 12) {
+        if (ND == 12 && MODE >= 1) {
             const T m = T(so100g::CUBE_MASS), I = T(so100g::CUBE_INERTIA);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
@@ -759,8 +770,8 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             if (MODE == 2) H[SO100_TRI(i, i)] += act ? Dl : T(0);
             zout |= act ? 4 << (3*i) : 0;
         }
-        if (MODE == 2 && !FORCED) { differ |= zout ^ zin; *zones = zout; }
-        if (MODE == 2 && !FORCED && same) *same = differ == 0;
+        if ((MODE == 2 || MODE == 0) && !FORCED) { differ |= zout ^ zin; *zones = zout; }
+        if ((MODE == 2 || MODE == 0) && !FORCED && same) *same = differ == 0;
     }
 
     // derivatives of phi(alpha) = cost(x + alpha dx) at alpha: d1 = phi', d2 = phi'' (of the current active set).  phi' is
@@ -829,7 +840,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 };
 
 #if !defined(__HIPCC__)
-static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0;     // host-only instrumentation
+static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0, g_dbg_cnewton_signpasses = 0, g_dbg_cnewton_gradpasses = 0;     // host-only instrumentation
 static int g_dbg_cnewton_trace = 0;
 #endif
 #if defined(SO100_CONTACT_STATS) && defined(__HIPCC__)
@@ -838,7 +849,7 @@ __device__ unsigned long long so100_cstats[8];          // calls, iterations, li
 #if defined(SO100_CONTACT_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define SO100_CSTAT(i) atomicAdd(&so100_cstats[i], 1ull)
 #elif !defined(__HIPCC__)
-#define SO100_CSTAT(i) ((i) == 3 || (i) == 2 ? (void)g_dbg_cnewton_passes++ : (void)0)
+#define SO100_CSTAT(i) ((i) == 3 || (i) == 2 ? (void)g_dbg_cnewton_passes++ : (i) == 5 ? (void)g_dbg_cnewton_signpasses++ : (i) == 6 ? (void)g_dbg_cnewton_gradpasses++ : (void)0)
 #else
 #define SO100_CSTAT(i) ((void)0)
 #endif
@@ -869,15 +880,56 @@ template <int ND, typename T> SO100_HD T grad_merit(const T g[ND]) {
     return E;
 }
 
+// y = H x for a packed-lower symmetric N x N matrix
+template <int N, typename T> SO100_HD void symn_mul(const T H[N*(N+1)/2], const T x[N], T y[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        T t = T(0);
+#pragma unroll
+        for (int j = 0; j < N; j++) t += (i >= j ? H[SO100_TRI(i, j)] : H[SO100_TRI(j, i)])*x[j];
+        y[i] = t;
+    }
+}
+
+// One step of iterative refinement of H dx = -g on the factor (L, Dinv) with the unfactored Hc: dx += H^-1 (-(g + Hc dx)).
+// Returns true when the step is LARGE relative to x (an impact: |g| is large, and the fp32 residual of the linear system is then
+// dominated by cancellation between g and Hc dx -- the caller refines with the gradient evaluated at the new point instead).
+template <int ND, typename T>
+SO100_HD bool lean_refine(const T* Hc, const T* L, const T* Dinv, const T g[ND], const T x[ND], T dx[ND]) {
+    T dmax = T(0), xmax = T(0);
+#pragma unroll
+    for (int i = 0; i < ND; i++) { dmax = tmax(dmax, tabs(dx[i])); xmax = tmax(xmax, tabs(x[i])); }
+    if (dmax > T(SO100_LEAN_ABS) + T(SO100_LEAN_DX)*xmax) return true;
+    T r[ND];
+    symn_mul<ND>(Hc, dx, r);
+#pragma unroll
+    for (int i = 0; i < ND; i++) r[i] = -(g[i] + r[i]);
+    ldln_solve<ND>(L, Dinv, r);
+#pragma unroll
+    for (int i = 0; i < ND; i++) dx[i] += r[i];
+    return false;
+}
+
+// LEAN (the 6-unknown problem: every default-physics solve).  The problem is piecewise quadratic, so after a FULL Newton step
+// x -> x + dx on the quadratic Q_S of an active set S the only open question is whether x + dx still selects S:
+//   * it does  => x + dx minimises the true cost.  No gradient or Hessian at the new point is needed to know that -- a pass
+//     that only evaluates the rows' signs (eval<0>: ~1/5 of a gradient + Hessian pass) answers it; the round-off of the step is
+//     removed by one iterative-refinement step of the LINEAR system on the Hessian that made the step (r = -(g + H dx) is the
+//     gradient of Q_S at x + dx; the unfactored H is kept for it: 21 registers);
+//   * it does not => gradient + Hessian of the set x + dx selects (eval<2> there), as before.
+// Round 2 ran a full gradient + Hessian pass + factorisation at every trial point just to learn `same`: 2 such passes per solve
+// in resting contact (1 + 1 sign pass now), 3.06 on average under the bench's random policy.
 template <int ND, typename T, class Store>
 SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND], bool warm, int* work = nullptr) {
     constexpr int NH = ND*(ND + 1)/2;
+    constexpr bool LEAN = ND == 6;
     const bool f32 = sizeof(T) == 4;
     T last = T(0);
 #if !defined(__HIPCC__)
     g_dbg_cnewton_calls++;
 #endif
-    T g[ND], H[NH];
+    T g[ND], H[NH], Hc[LEAN ? NH : 1];
+    bool same = false;
     if (warm) {
         // Active-set warm start.  The rows are stiff (a force-carrying row sits at jar = -R f, a hair below zero), so the sign of jar at
         // the previous acceleration says nothing about which rows will carry force now -- the previous substep's final active set does.
@@ -887,20 +939,43 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         P.template eval<2, true>(x, g, H);
         if (work) *work += 1;
         SO100_CSTAT(3);
+        if (LEAN) {
+#pragma unroll
+            for (int i = 0; i < NH; i++) Hc[i] = H[i];
+        }
 #pragma unroll
         for (int i = 0; i < ND; i++) dx[i] = -g[i];
         ldln<ND>(H, Dinv);
         ldln_solve<ND>(H, Dinv, dx);
+        bool big = false;
+        if (LEAN) big = lean_refine<ND>(Hc, H, Dinv, g, x, dx);
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += dx[i];
+        if (LEAN) {
+            P.template eval<0>(x, g, H, &same);               // signs only: does x select the remembered set? (records the set it selects)
+            if (work) *work += 1;
+            SO100_CSTAT(5);
+            if (same && !big) return T(0);
+            if (same) {                                       // a large step: its round-off is removed with the gradient evaluated AT the new point
+                P.template eval<1>(x, g, Hc);                 // (Hc is not written by a gradient pass; H holds the factor)
+                if (work) *work += 1;
+                SO100_CSTAT(6);
+#pragma unroll
+                for (int i = 0; i < ND; i++) dx[i] = -g[i];
+                ldln_solve<ND>(H, Dinv, dx);
+#pragma unroll
+                for (int i = 0; i < ND; i++) x[i] += dx[i];
+                return T(0);
+            }
+        }
     }
-    bool same = false;
     P.template eval<2>(x, g, H, &same);
     if (work) *work += 1;
     SO100_CSTAT(0); SO100_CSTAT(3);
     // onq: x came from a full Newton step on the quadratic of the very active set it selects, i.e. it IS the minimiser up to the
-    // round-off of that step; one more step on the same quadratic (iterative refinement) and the solve ends without a verifying pass
-    bool onq = warm && same;
+    // round-off of that step; one more step on the same quadratic (iterative refinement) and the solve ends without a verifying pass.
+    // (LEAN: that case has returned above; here the remembered set is the one x selects since the sign pass, `same` says nothing.)
+    bool onq = !LEAN && warm && same;
     T E0 = grad_merit<ND>(g);
     bool small_prev = false;                                  // the previous step was small and brought no progress in the merit
     for (int it = 0; it < iters; it++) {
@@ -910,6 +985,10 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #if !defined(__HIPCC__)
         g_dbg_cnewton_iters++;
 #endif
+        if (LEAN) {
+#pragma unroll
+            for (int i = 0; i < NH; i++) Hc[i] = H[i];
+        }
 #pragma unroll
         for (int i = 0; i < ND; i++) dx[i] = -g[i];
         ldln<ND>(H, Dinv);
@@ -936,10 +1015,36 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         T xn[ND], gn[ND];
 #pragma unroll
         for (int i = 0; i < ND; i++) xn[i] = x[i] + dx[i];
+        if (LEAN) {
+            // the remembered set is the one x selects (the plain pass at x recorded it): did the full step stay on its quadratic?
+            P.template eval<0>(xn, gn, H, &same);
+            if (work) *work += 1;
+            SO100_CSTAT(5);
+            if (same) {                                       // (H still holds the factor of the step's Hessian: eval<0> does not touch it)
+                T d2[ND];
+#pragma unroll
+                for (int i = 0; i < ND; i++) d2[i] = dx[i];
+                const bool big = lean_refine<ND>(Hc, H, Dinv, g, x, d2);
+#pragma unroll
+                for (int i = 0; i < ND; i++) x[i] += d2[i];
+                if (big) {
+                    P.template eval<1>(x, gn, Hc);
+                    if (work) *work += 1;
+                    SO100_CSTAT(6);
+#pragma unroll
+                    for (int i = 0; i < ND; i++) d2[i] = -gn[i];
+                    ldln_solve<ND>(H, Dinv, d2);
+#pragma unroll
+                    for (int i = 0; i < ND; i++) x[i] += d2[i];
+                }
+                last = T(0);
+                break;
+            }
+        }
         P.template eval<2>(xn, gn, H, &same);                 // gradient + Hessian at the trial point: next iteration's, if accepted
         if (work) *work += 1;
         SO100_CSTAT(3);
-        if (same) {                                           // the full step stayed on its quadratic: the minimiser, up to round-off
+        if (!LEAN && same) {                                  // the full step stayed on its quadratic: the minimiser, up to round-off
 #pragma unroll
             for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
             onq = true; last = T(0);

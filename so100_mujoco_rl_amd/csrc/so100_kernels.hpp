@@ -203,7 +203,15 @@ __global__ void __launch_bounds__(WG) so100_init_state(int n, float* state) {
 }
 
 
-constexpr int MW_MAX_ENVS = 16384;   // up to here the 4-wave step kernel wins (256 CUs x 64 envs); beyond, the chip is full anyway
+// Which step kernel for which batch (so100_create fills SimParams::mw_max from this; SO100_MW_MAX_ENVS in the environment overrides it
+// for measurements).  The 4-wave kernel so100_step_mw splits one env step over 4 waves: lowest latency, and it wins while the batch
+// leaves SIMDs idle (256 CUs x 64 envs = 16384).  Beyond that the one-wave kernel so100_step_fused has the higher throughput for the
+// variants whose substep fits the register file -- but the pad-contact variants need 1.0-1.5 KB of scratch per lane there (the contact
+// Newton next to the env state) while so100_step_mw<K, 23 | 55> runs with none, so for them the 4-wave kernel stays ahead at every batch
+// size measured (profiles/r03_large_batch_dispatch.txt).
+constexpr int MW_MAX_ENVS = 16384;
+constexpr int MW_MAX_ENVS_PADS = 16384;    // (provisional: set from the measurement)
+inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
 struct RolloutPtrs { float* obs; float* rew; uint8_t* done; uint8_t* trunc; float* tobs; float* ep_ret; int32_t* ep_len; };
@@ -231,7 +239,7 @@ template <int KIND> int KindOps<KIND>::prof_read_wg(long long* wg, int* env) {
 #endif
 
 template <int KIND> hipError_t KindOps<KIND>::step(const SimParams& prm, const StepPtrs& io, hipStream_t st) {
-    const bool mw = prm.n <= MW_MAX_ENVS;
+    const bool mw = prm.n <= prm.mw_max;
     const dim3 g = mw ? dim3((unsigned)((prm.n + prm.epw - 1)/prm.epw)) : grid_for(prm.n), b(mw ? 256 : WG);
 #define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, prm, io); \
                              else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, prm, io); } while (0)

@@ -108,6 +108,8 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
             while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
         s->prm.epw = epw;
+        s->prm.mw_max = mw_max_envs_for(cfg->flags);
+        if (const char* ov = getenv("SO100_MW_MAX_ENVS")) { const long v = atol(ov); if (v >= 0) s->prm.mw_max = (int32_t)(v > (1L << 30) ? (1L << 30) : v); }
     }
     const size_t bytes = (size_t)SF_COUNT*(size_t)cfg->num_envs*sizeof(float);
     if (hipMalloc(&s->state, bytes) != hipSuccess) { delete s; return fail(SO100_E_NOMEM, "so100_create: hipMalloc of %s%ld bytes failed", "", (long)bytes); }

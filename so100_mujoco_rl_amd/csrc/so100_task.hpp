@@ -21,6 +21,7 @@ struct SimParams {
     int32_t  solver_iters, contact_iters, frame_skip, max_episode_steps;
     uint32_t seed_lo, seed_hi, env_id_offset;
     int32_t  epw;                // envs per workgroup of the multi-wave kernels (64, 32 or 16 lanes of each wave in use)
+    int32_t  mw_max;             // so100_step: batches up to this size take the 4-wave kernel so100_step_mw, larger ones so100_step_fused
 };
 
 // State of a lane that owns no env (tail of the last workgroup, or lanes >= epw): it must not make its wave wait.  An all-zero

@@ -154,14 +154,39 @@ class So100Sim:
         self.kind = env_kind
         self.obs_dim = self.L.so100_obs_dim(env_kind)
         kw = dict(device=self.device)
-        self.obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
-        self.rew = torch.zeros(num_envs, dtype=torch.float32, **kw)
-        self.done = torch.zeros(num_envs, dtype=torch.uint8, **kw)
-        self.trunc = torch.zeros(num_envs, dtype=torch.uint8, **kw)
-        self.terminal_obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
-        self.ep_return = torch.zeros(num_envs, dtype=torch.float32, **kw)
-        self.ep_length = torch.zeros(num_envs, dtype=torch.int32, **kw)
+        # the handle's device-side outputs (read through the properties below: a step_host() leaves them stale until then)
+        self._obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
+        self._rew = torch.zeros(num_envs, dtype=torch.float32, **kw)
+        self._done = torch.zeros(num_envs, dtype=torch.uint8, **kw)
+        self._trunc = torch.zeros(num_envs, dtype=torch.uint8, **kw)
+        self._terminal_obs = torch.zeros(num_envs, self.obs_dim, dtype=torch.float32, **kw)
+        self._ep_return = torch.zeros(num_envs, dtype=torch.float32, **kw)
+        self._ep_length = torch.zeros(num_envs, dtype=torch.int32, **kw)
+        self._host_out = None        # pinned host buffers of the last step_host() while they are newer than the device tensors
         self._io = StepIO()
+
+    # obs / rew / done / trunc / terminal_obs / ep_return / ep_length: device tensors, always current.  step_host() writes its
+    # results to the caller's pinned host buffers only; the first read of any of these afterwards (a checkpoint, the rollout
+    # collector, policy_forward on sim.obs ...) mirrors them back to the device, on the current stream, once.
+    def _refresh(self):
+        h = self._host_out
+        if h is not None:
+            self._host_out = None
+            for dst, src in zip((self._obs, self._rew, self._done, self._trunc), h[:4]):
+                dst.copy_(src, non_blocking=True)
+            done = self._done != 0                      # terminal_obs / episode statistics are only written where an episode ended
+            for dst, src in zip((self._terminal_obs, self._ep_return, self._ep_length), h[4:]):
+                if src is not None:
+                    m = done if dst.dim() == 1 else done[:, None]
+                    dst.copy_(torch.where(m, src.to(self.device, non_blocking=True), dst))
+
+    obs = property(lambda self: (self._refresh(), self._obs)[1])
+    rew = property(lambda self: (self._refresh(), self._rew)[1])
+    done = property(lambda self: (self._refresh(), self._done)[1])
+    trunc = property(lambda self: (self._refresh(), self._trunc)[1])
+    terminal_obs = property(lambda self: (self._refresh(), self._terminal_obs)[1])
+    ep_return = property(lambda self: (self._refresh(), self._ep_return)[1])
+    ep_length = property(lambda self: (self._refresh(), self._ep_length)[1])
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -198,12 +223,16 @@ class So100Sim:
     def step_host(self, act, obs, rew, done, trunc, terminal_obs=None, ep_return=None, ep_length=None):
         """The same env step with every boundary buffer in PINNED HOST memory: the kernel reads the actions and writes its results
         over the host link itself -- one launch, no copy nodes (So100VecEnv's numpy path: 62 instead of 94 us per step at 4096 envs).
-        The results are valid after the stream is synchronised; the handle's device-side obs / rew / done tensors are NOT updated."""
+        The results are valid after the stream is synchronised; the handle's device-side obs / rew / done ... tensors are refreshed
+        from these buffers lazily, on their next read (`_refresh`) -- so the buffers must stay alive and unmodified until then
+        (So100VecEnv owns them and only the next step_host() overwrites them, stream-ordered after the refresh)."""
+        self._refresh()                                 # an older pending mirror must land before this step overwrites its source
         io = StepIO(_hptr(act, torch.float32, (self.n, 6)), _hptr(obs, torch.float32, (self.n, self.obs_dim)), _hptr(rew, torch.float32, (self.n,)),
                     _hptr(done, torch.uint8, (self.n,)), _hptr(trunc, torch.uint8, (self.n,)),
                     _hptr(terminal_obs, torch.float32, (self.n, self.obs_dim)), _hptr(ep_return, torch.float32, (self.n,)),
                     _hptr(ep_length, torch.int32, (self.n,)), None, None)
         _check(self.L.so100_step(self.h, C.byref(io), self._stream()), "so100_step")
+        self._host_out = (obs, rew, done, trunc, terminal_obs, ep_return, ep_length)
 
     def set_policy(self, tensors):
         """tensors: dict name -> float32 device tensor (names: POLICY_TENSORS; SB3 keys: SB3_STATE_DICT_KEYS)."""
@@ -284,7 +313,8 @@ class So100Sim:
         for row, n in zip(words, names):
             if self.L.so100_state_field_index(n.encode()) >= 0:
                 self.set_field(n, torch.from_numpy(row).to(self.device))
-        self.obs.copy_(torch.from_numpy(obs))
+        self._host_out = None
+        self._obs.copy_(torch.from_numpy(obs))
 
     def bad_state_mask(self):
         """bool [N]: envs whose episode was ever ended by the non-finite state guard (NaN / inf action or state)."""

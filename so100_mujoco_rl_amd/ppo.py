@@ -109,4 +109,8 @@ class PPO:
                 S["idx"] = perm[i:i + mb]
                 self.opt.zero_grad(set_to_none=True); self._step()
         S["idx"] = torch.zeros(mb, dtype=torch.long, device=self.device)
-        return {"value_loss": S["vl"].item(), "mean_reward": S["rewards"].mean().item()}
+        # mean_reward = the ENV's mean reward per step (the collector takes it before its TimeLimit bootstrap adds gamma * V to the
+        # truncated steps); S["rewards"] holds the bootstrapped rewards the advantages are computed from
+        raw = b.get("raw_reward_mean")
+        return {"value_loss": S["vl"].item(), "mean_reward": (raw if raw is not None else S["rewards"].mean()).item(),
+                "mean_bootstrapped_reward": S["rewards"].mean().item()}

@@ -65,6 +65,13 @@ def gather_rollout(chunk_buf, dst=0, group=None):
     return torch.cat(out, dim=1) if rank == dst else None
 
 
+def mean_over_ranks(x, group=None):
+    """mean of a per-rank scalar statistic (equal shard sizes); every rank calls it"""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        x = x.clone(); dist.all_reduce(x, group=group); x = x / dist.get_world_size(group)
+    return x
+
+
 def broadcast_policy(tensors, src=0, group=None):
     """Send the learner's updated policy weights (SB3 MlpPolicy: ~11k parameters) back to every rank."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:

@@ -96,6 +96,8 @@ int hc_boxbox_f(const double* cA, const double* RA, const double* hA, const doub
 void hc_cdbg_trace(int on) { g_dbg_cnewton_trace = on; }
 void hc_cdbg_counters(long* out) { out[0] = g_dbg_cnewton_calls; out[1] = g_dbg_cnewton_iters; out[2] = g_dbg_cnewton_ls; }
 long hc_cdbg_passes(void) { return g_dbg_cnewton_passes; }
+long hc_cdbg_signpasses(void) { return g_dbg_cnewton_signpasses; }
+long hc_cdbg_gradpasses(void) { return g_dbg_cnewton_gradpasses; }
 int hc_contact_id_hash(int id) { return contact_id_hash(id); }
 }
 

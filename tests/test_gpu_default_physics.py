@@ -42,7 +42,7 @@ def _start(env, col, qpos, qvel, kind):
 def test_default_rollout_kernel_vs_stepwise_and_oracle(kind, flags):
     from so100_mujoco_rl_amd.vec_env import So100VecEnv
     from so100_mujoco_rl_amd.collector import RolloutCollector
-    n, T, tl = 200, 10, 7                                    # tail workgroup partially filled; TimeLimit hits inside the chunk
+    n, T, T2, tl = 200, 10, 5, 12                            # tail workgroup partially filled; a second, shorter chunk; TimeLimit hits inside it
     qpos, qvel = _contact_rich_state(n, flags, 10 + kind)
     runs = []
     for persistent in (True, False):
@@ -55,8 +55,14 @@ def test_default_rollout_kernel_vs_stepwise_and_oracle(kind, flags):
         col = RolloutCollector(env, sd, T=T, persistent=persistent, bootstrap_truncated=False)
         _start(env, col, qpos, qvel, kind)
         b = {k: v.clone() for k, v in col.collect().items()}
+        cs1 = env.sim.get_field("contact_stat", dtype=torch.int32).clone()      # (before the TimeLimit sends every arm back to its start pose)
+        b2 = {k: v.clone() for k, v in col.collect(T2).items()}
+        for k in ("obs", "actions", "rewards", "dones", "values", "log_probs"):
+            b[k] = torch.cat([b[k], b2[k]], 0)
+        b["last_obs"] = b2["last_obs"]
         q, v = env.sim.get_state()
-        runs.append((b, q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone()))
+        runs.append((b, q.clone(), v.clone(), cs1))
+    T = T + T2
     (a, aq, av, acs), (s, sq, sv, scs) = runs
     # ---- persistent kernel vs stepwise kernels: the same actions (the policy noise stream is shared), so rows can be compared one by one
     assert torch.equal(a["dones"], s["dones"]) and a["dones"].sum() > 0
@@ -87,7 +93,7 @@ def test_default_rollout_kernel_vs_stepwise_and_oracle(kind, flags):
                 classes["fail"] += 1
     touched = float(((acs & 255) > 0).float().mean())
     print(f"[default rollout kernel, kind {kind} flags {flags}] persistent vs stepwise: {tight:.3f} of rows within 1e-5, {loose:.3f} within 2e-2; "
-          f"vs oracle ({len(sample)} envs x {T} steps): {classes}, median err {np.median(errs):.2e}; envs with a pad contact in the last step {touched:.2f}")
+          f"vs oracle ({len(sample)} envs x {T} steps): {classes}, median err {np.median(errs):.2e}; envs with a pad contact in step 10 {touched:.2f}")
     assert torch.isfinite(a["obs"]).all() and torch.isfinite(a["rewards"]).all() and torch.isfinite(aq).all() and torch.isfinite(av).all()
     assert touched > 0.2                                     # the contact path really ran
     assert (acs >> 8).max() == 0 and (scs >> 8).max() == 0   # nothing over the contact budget

@@ -814,6 +814,32 @@ def test_vecenv_zero_copy_round_trip_equals_staged():
     eg.close(); ee.close()
 
 
+def test_device_outputs_stay_current_after_numpy_steps(tmp_path):
+    """So100VecEnv's zero-copy numpy path writes its results to pinned host memory only; the handle's device tensors (sim.obs, ...)
+    that a checkpoint, the rollout collector or policy_forward read must still be the CURRENT ones afterwards."""
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n = 130
+    env = So100VecEnv("Env01-v1", n, flags=ARM, seed=6, max_episode_steps=5)
+    env.reset()
+    rs = np.random.RandomState(0)
+    for t in range(7):                                       # crosses a TimeLimit reset
+        ob, rw, dn, infos = env.step(rs.uniform(-1, 1, (n, 6)).astype(np.float32))
+    assert env._zero_copy
+    np.testing.assert_array_equal(env.sim.obs.cpu().numpy(), ob)
+    np.testing.assert_array_equal(env.sim.rew.cpu().numpy(), rw); np.testing.assert_array_equal(env.sim.done.cpu().numpy().astype(bool), dn)
+    # checkpoint -> restore into a fresh handle: the stored observation is the last returned one, not the reset observation
+    path = str(tmp_path / "sim.npz"); env.sim.save_state(path)
+    env2 = So100VecEnv("Env01-v1", n, flags=ARM, seed=6, max_episode_steps=5); env2.reset(); env2.sim.load_state(path)
+    np.testing.assert_array_equal(env2.sim.obs.cpu().numpy(), ob)
+    # numpy steps, then the on-device collector: its first policy forward sees the current observation
+    ob2 = env.step(rs.uniform(-1, 1, (n, 6)).astype(np.float32))[0]
+    col = RolloutCollector(env, RolloutCollector.random_policy_state(15, env.device, seed=1), T=4, persistent=True); col._started = True
+    b = col.collect()
+    np.testing.assert_array_equal(b["obs"][0].cpu().numpy(), ob2)
+    env.close(); env2.close()
+
+
 @pytest.mark.parametrize("n,frame_skip", [(1, 16), (63, 5), (65, 1), (130, 7)])
 def test_odd_batch_sizes_and_frame_skips_vs_oracle(n, frame_skip):
     """Tail workgroups (N not a multiple of 64, N = 1) and frame_skip values other than the reference's 16, against the oracle."""

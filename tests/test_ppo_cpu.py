@@ -62,3 +62,24 @@ def test_truncation_is_bootstrapped_then_gae_matches_hand_computation():
     # the truncated step's TD target really contains the bootstrap: delta = r + gamma V(tobs) - V_t (no V_{t+1} leak)
     d20 = raw_rew[2, 0] + gamma * (float(tobs[2, 0] @ w) + 0.25) - float(b["values"][2, 0])
     np.testing.assert_allclose(hand[2, 0], d20, rtol=1e-6)
+
+
+def test_reported_mean_reward_is_the_env_reward_not_the_bootstrapped_one():
+    """model selection / early stopping in main.py read stats["mean_reward"]: it must be the env's reward, unchanged by the
+    gamma * V(terminal_observation) the collector adds on truncated steps (every episode end of Env01/02/06 is a truncation)"""
+    T, N, OD = 8, 4, 15
+    rs = np.random.RandomState(1)
+    chunk = RolloutChunk(T, N, OD, "cpu")
+    chunk.buf.copy_(torch.from_numpy(rs.randn(T, N, OD + 10).astype(np.float32)))
+    code = np.zeros((T, N), np.float32); code[3, :] = 2.0; code[7, 1] = 2.0
+    chunk.buf[..., OD + 7] = torch.from_numpy(code)
+    raw_mean = chunk.buf[..., OD + 6].mean().clone()
+    tobs = torch.from_numpy(rs.randn(T, N, OD).astype(np.float32))
+    bootstrap_truncated(chunk.buf[..., OD + 6], chunk.buf[..., OD + 7], tobs, lambda x: torch.full((x.shape[0],), 50.0), 0.99)   # an over-estimating critic
+    b = chunk.unpack(); b["last_obs"] = torch.zeros(N, OD); b["raw_reward_mean"] = raw_mean
+    ppo = PPO(OD, "cpu", use_graph=False)
+    stats = ppo.update(b)
+    assert abs(stats["mean_reward"] - float(raw_mean)) < 1e-6
+    assert stats["mean_bootstrapped_reward"] > stats["mean_reward"] + 5.0          # 5 of 32 steps got +49.5
+    del b["raw_reward_mean"]                                                         # a caller without the statistic: falls back to the buffer's mean
+    assert abs(ppo.update(b)["mean_reward"] - stats["mean_bootstrapped_reward"]) < 1e-5
