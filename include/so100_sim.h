@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SO100_ABI_VERSION 2
+#define SO100_ABI_VERSION 3
 
 /* env kinds == the reference's registered ids Env01-v1 .. Env06-v1 (ref: __init__.py:5-45) */
 #define SO100_ENV01 1   /* ref: envs/env01_v1.py  reach, random start pose              obs 15 */
@@ -72,7 +72,11 @@ typedef struct {
     int32_t  max_episode_steps;   /* TimeLimit: 4000 Env01, 6000 others (ref: __init__.py:8,15); 0 = none */
     uint64_t seed;                /* Philox key                                                    */
     uint32_t env_id_offset;       /* global id of env 0 (rank * N): makes sharded runs reproducible */
-    uint32_t reserved;
+    uint32_t envs_per_workgroup;  /* 0 = chosen by the library from N and the CU count (16 / 32 / 64 lanes of each 64-lane wave own an env in the
+                                     multi-wave kernels; the pad-contact solve sums its records over the 4 / 2 / 1 lanes of an env in that
+                                     order).  Results are bitwise reproducible for a given value; two handles that must agree bit for bit on
+                                     the same envs although their N differs (a batch split into shards of another size) pass the same value:
+                                     16, 32 or 64.  so100_envs_per_workgroup() reads it back. */
 } so100_config;
 
 /* One vectorised env step.  Replaces, for N envs at once, the reference chain
@@ -160,6 +164,7 @@ const char* so100_state_field_name(int32_t field);        /* inverse of the abov
  * (envs/env_base_01.py:35-51).  The model is compiled in (csrc/so100_model_def.h). */
 int  so100_create(const so100_config* cfg, so100_sim** out);
 void so100_destroy(so100_sim* sim);
+int  so100_envs_per_workgroup(const so100_sim* sim);      /* the value in use (see so100_config); < 0 on a null handle */
 
 /* ref: MujocoEnv.reset -> mj_resetData -> EnvNN.reset_model (envs/env01_v1.py:39-63 and clones).
  * mask_dev: [N] bytes, non-zero = reset that env; NULL = all.  obs_dev rows of untouched envs are left alone. */

@@ -854,6 +854,7 @@ __device__ unsigned long long so100_cstats[8];          // calls, iterations, li
 #define SO100_CSTAT(i) ((void)0)
 #endif
 
+// (`work`, profiling builds only: += 1 per gradient + Hessian pass, 1 << 8 per sign pass, 1 << 16 per gradient pass, 1 << 24 per line-search pass.)
 // Newton on the primal problem.  x: warm start in, solution out.  Returns the size of the last Newton step when the
 // iteration budget ran out before the solve ended (0 otherwise): the solver residual a caller can watch.
 //
@@ -953,12 +954,12 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         for (int i = 0; i < ND; i++) x[i] += dx[i];
         if (LEAN) {
             P.template eval<0>(x, g, H, &same);               // signs only: does x select the remembered set? (records the set it selects)
-            if (work) *work += 1;
+            if (work) *work += 1 << 8;
             SO100_CSTAT(5);
             if (same && !big) return T(0);
             if (same) {                                       // a large step: its round-off is removed with the gradient evaluated AT the new point
                 P.template eval<1>(x, g, Hc);                 // (Hc is not written by a gradient pass; H holds the factor)
-                if (work) *work += 1;
+                if (work) *work += 1 << 16;
                 SO100_CSTAT(6);
 #pragma unroll
                 for (int i = 0; i < ND; i++) dx[i] = -g[i];
@@ -1018,7 +1019,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
         if (LEAN) {
             // the remembered set is the one x selects (the plain pass at x recorded it): did the full step stay on its quadratic?
             P.template eval<0>(xn, gn, H, &same);
-            if (work) *work += 1;
+            if (work) *work += 1 << 8;
             SO100_CSTAT(5);
             if (same) {                                       // (H still holds the factor of the step's Hessian: eval<0> does not touch it)
                 T d2[ND];
@@ -1029,7 +1030,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
                 for (int i = 0; i < ND; i++) x[i] += d2[i];
                 if (big) {
                     P.template eval<1>(x, gn, Hc);
-                    if (work) *work += 1;
+                    if (work) *work += 1 << 16;
                     SO100_CSTAT(6);
 #pragma unroll
                     for (int i = 0; i < ND; i++) d2[i] = -gn[i];
@@ -1076,7 +1077,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 #pragma unroll 1
         for (int ls = 0; ls < (f32 ? (ND == 12 ? 6 : SO100_LS_PASSES) : 40); ls++) {      // (the coupled problem with its 8 g cube needs the better minimiser)
             P.line_deriv(x, dx, alpha, d1, d2);
-            if (work) *work += 1;
+            if (work) *work += 1 << 24;
             SO100_CSTAT(2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;

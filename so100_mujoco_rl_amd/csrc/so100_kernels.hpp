@@ -226,11 +226,17 @@ template <int KIND> struct KindOps {
 #ifdef SO100_ROLLOUT_PROF
     static int prof_read(long long* out48);       // the cycle counters live in the kind's own code object
     static int prof_read_wg(long long* wg4096, int* env32768);
+    static int prof_read_hist(unsigned long long* hist48, int reset);
 #endif
 };
 #ifdef SO100_ROLLOUT_PROF
 template <int KIND> int KindOps<KIND>::prof_read(long long* out48) {
     return hipMemcpyFromSymbol(out48, HIP_SYMBOL(so100_prof), sizeof(long long)*48) == hipSuccess ? 0 : -1;
+}
+template <int KIND> int KindOps<KIND>::prof_read_hist(unsigned long long* h, int reset) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(so100_prof_hist), sizeof(unsigned long long)*48) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[48] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(so100_prof_hist), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
 }
 template <int KIND> int KindOps<KIND>::prof_read_wg(long long* wg, int* env) {
     if (hipMemcpyFromSymbol(wg, HIP_SYMBOL(so100_prof_wg), sizeof(long long)*4096) != hipSuccess) return -1;
@@ -243,7 +249,7 @@ template <int KIND> hipError_t KindOps<KIND>::step(const SimParams& prm, const S
     const dim3 g = mw ? dim3((unsigned)((prm.n + prm.epw - 1)/prm.epw)) : grid_for(prm.n), b(mw ? 256 : WG);
 #define SO100_STEP(FLV) do { if (mw) hipLaunchKernelGGL((so100_step_mw<KIND, FLV>), g, b, 0, st, prm, io); \
                              else    hipLaunchKernelGGL((so100_step_fused<KIND, FLV>), g, b, 0, st, prm, io); } while (0)
-#define SO100_STEP_ROWS(FLV) do { if (prm.n >= DENSE_MIN_ENVS) hipLaunchKernelGGL((so100_step_fused<KIND, FLV, true>), g, b, 0, st, prm, io); \
+#define SO100_STEP_ROWS(FLV) do { if (!mw && prm.n >= DENSE_MIN_ENVS) hipLaunchKernelGGL((so100_step_fused<KIND, FLV, true>), g, b, 0, st, prm, io); \
                                   else SO100_STEP(FLV); } while (0)
     switch (prm.flags) {
     case SO100_F_CUBE_PINNED: SO100_STEP(SO100_F_CUBE_PINNED); break;

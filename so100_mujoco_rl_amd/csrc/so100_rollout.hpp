@@ -24,6 +24,7 @@ struct RolloutArgs {
     uint32_t step_counter0;      // policy-noise Philox counter of the first step
     const float* obs_in;         // [N][OD] current observation (reset or previous launch)
     float* tobs_chunk;           // [T][N][OD] terminal observation of every episode end inside the chunk (written where done); nullable
+    const int32_t* slot_env;     // [workgroups x epw] env of every lane slot, -1 = none (so100_balance.hpp); null = identity (slot s holds env s)
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -34,9 +35,34 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ long long so100_prof[48];
 __device__ long long so100_prof_wg[1024*4];    // per workgroup: wave 0 total, wave 3 narrowphase, wave 3 contact Newton, wave 0 barrier-3 wait
 __device__ int so100_prof_env[16384*2];        // per env: row passes of the contact Newton, substeps with a pad contact (this launch)
+// per (workgroup, substep): [0..15] histogram of the slowest lane's gradient + Hessian passes (where any lane solved), [16..32] histogram of the number of
+// envs in pad contact, [33..36] passes of all envs by type (full, sign, gradient, line search), [37] sum of the slowest lane's estimated instruction
+// count (970 / 140 / 520 / 300 per pass type), [38] (workgroup, substep) pairs with a solve, [39] all pairs, [40] sum over ENVS of that estimate
+__device__ unsigned long long so100_prof_hist[48];
 struct Prof {
     long long t[10] = {}, c = __builtin_readcyclecounter();
-    int work = 0, insub = 0;
+    int work = 0, insub = 0, sub = 0;
+    // wave 3, once per substep (all its lanes): `sub` holds this substep's typed pass counts of the lane's env (0 if it did not solve)
+    __device__ __forceinline__ void substep_stats(bool solved, bool first_of_env) {
+        const int f = sub & 255, s = (sub >> 8) & 255, g = (sub >> 16) & 255, l = (sub >> 24) & 255;
+        work += f + s + g + l;
+        int cost = solved ? 970*f + 140*s + 520*g + 300*l : 0, fmaxl = solved ? f : 0;
+        const unsigned long long m = __ballot(solved && first_of_env);
+        int best = cost, bf = fmaxl;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const int oc = __shfl_xor(best, d, 64), of = __shfl_xor(bf, d, 64); if (oc > best) { best = oc; bf = of; } }
+        if (solved && first_of_env) {
+            atomicAdd(&so100_prof_hist[33], (unsigned long long)f); atomicAdd(&so100_prof_hist[34], (unsigned long long)s);
+            atomicAdd(&so100_prof_hist[35], (unsigned long long)g); atomicAdd(&so100_prof_hist[36], (unsigned long long)l);
+            atomicAdd(&so100_prof_hist[40], (unsigned long long)cost);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const int ne = __popcll(m);
+            atomicAdd(&so100_prof_hist[16 + (ne > 16 ? 16 : ne)], 1ull); atomicAdd(&so100_prof_hist[39], 1ull);
+            if (m) { atomicAdd(&so100_prof_hist[bf > 15 ? 15 : bf], 1ull); atomicAdd(&so100_prof_hist[37], (unsigned long long)best); atomicAdd(&so100_prof_hist[38], 1ull); }
+        }
+        sub = 0;
+    }
     __device__ __forceinline__ void mark(int slot) { const long long n = __builtin_readcyclecounter(); t[slot] += n - c; c = n; }
     __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 10; i++) so100_prof[base + i] = t[i]; }
     __device__ __forceinline__ void flush_wg(int wave, int lane, int env, bool live) const {
@@ -48,10 +74,11 @@ struct Prof {
         if (wave == 3 && live && env < 16384) { so100_prof_env[2*env] = work; so100_prof_env[2*env + 1] = insub; }
     }
 };
-#define SO100_PROF_WORK (&prof_.work)
+#define SO100_PROF_WORK (&prof_.sub)
 #define SO100_PROF_INSUB() (prof_.insub++)
 #else
 struct Prof {
+    __device__ __forceinline__ void substep_stats(bool, bool) {}
     __device__ __forceinline__ void mark(int) {}
     __device__ __forceinline__ void flush(int, bool) const {}
     __device__ __forceinline__ void flush_wg(int, int, int, bool) const {}
@@ -292,6 +319,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             forget_caller_state();
             SO100_PROF(6);                                 // contact Newton (wave 3)
         }
+        if (wave == 3 && pads) prof_.substep_stats(cs3.n > 0, part3 == 0);      // (profiling builds only)
         if (pads) __syncthreads();                         // the contact wave's accelerations are in xa
         SO100_PROF(8);                                     // barrier 3 wait
         if (wave == 0) {
@@ -518,8 +546,11 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int env = blockIdx.x*p.epw + lane;                       // p.epw lanes of each wave own an env (64, or fewer to spread a small batch over all CUs)
-    const bool live = lane < p.epw && env < p.n;
+    // p.epw lanes of each wave own an env (64, or fewer to spread a small batch over all CUs); WHICH env a slot holds is the launcher's
+    // choice (so100_balance.hpp deals contact-prone envs out over the workgroups): results do not depend on it
+    const int slot = blockIdx.x*p.epw + lane;
+    const int env = lane < p.epw ? (ra.slot_env ? ra.slot_env[slot] : (slot < p.n ? slot : -1)) : -1;
+    const bool live = env >= 0;
     const int tower = wave >> 1, rt = wave & 1;
     const int lj = lane & 31, lh = lane >> 5;
     // ---- once per launch: weight fragments -> registers, head weights -> LDS, env state -> registers, obs -> LDS

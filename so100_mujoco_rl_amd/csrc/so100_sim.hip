@@ -1,6 +1,7 @@
 // so100_sim.hip -- the C ABI of libso100sim.so (include/so100_sim.h).  The kernels live in so100_kernels.hpp; their per-kind
 // instantiations are compiled in so100_kind.hip (one object per env kind), this file only dispatches to them.
 #include "so100_kernels.hpp"
+#include "so100_balance.hpp"
 
 namespace so100 {
 extern template struct KindOps<1>; extern template struct KindOps<2>; extern template struct KindOps<3>;
@@ -34,6 +35,7 @@ struct so100_sim {
     SimParams prm;
     float* state = nullptr;        // [SF_COUNT][N]
     float* start_tab = nullptr;    // [36][6]
+    int32_t* slot_env = nullptr;   // [workgroups x epw] lane-slot map of the persistent rollout kernel (pad-contact variants; so100_balance.hpp)
 };
 
 namespace {
@@ -66,6 +68,7 @@ const char* so100_last_error(void) { return g_err; }
 #ifdef SO100_ROLLOUT_PROF
 int so100_prof_read(int kind, long long* out48) { return DISPATCH_KIND(kind, prof_read)(out48); }
 int so100_prof_read_wg(int kind, long long* wg4096, int* env32768) { return DISPATCH_KIND(kind, prof_read_wg)(wg4096, env32768); }
+int so100_prof_read_hist(int kind, unsigned long long* hist48, int reset) { return DISPATCH_KIND(kind, prof_read_hist)(hist48, reset); }
 #endif
 
 int so100_create(const so100_config* cfg, so100_sim** out) {
@@ -81,6 +84,8 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         return fail(SO100_E_INVALID, "so100_create: unknown flag bits%s");
     if ((cfg->flags & SO100_F_PADS_CUBE) && (cfg->flags & SO100_F_CUBE_PINNED))
         return fail(SO100_E_INVALID, "so100_create: SO100_F_PADS_CUBE needs a dynamic cube (not SO100_F_CUBE_PINNED)%s");
+    if (cfg->envs_per_workgroup != 0 && cfg->envs_per_workgroup != 16 && cfg->envs_per_workgroup != 32 && cfg->envs_per_workgroup != 64)
+        return fail(SO100_E_INVALID, "so100_create: envs_per_workgroup must be 0 (automatic), 16, 32 or 64%s");
     if ((cfg->flags & SO100_F_FLOOR) && (cfg->flags & SO100_F_CUBE_PINNED))
         return fail(SO100_E_INVALID, "so100_create: SO100_F_FLOOR and SO100_F_CUBE_PINNED are mutually exclusive%s");
     int ndev = 0;
@@ -107,6 +112,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         int epw = 64;
         if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
             while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
+        if (cfg->envs_per_workgroup != 0) epw = (int)cfg->envs_per_workgroup;             // the caller pins it (validated above)
         s->prm.epw = epw;
         s->prm.mw_max = mw_max_envs_for(cfg->flags);
         if (const char* ov = getenv("SO100_MW_MAX_ENVS")) { const long v = atol(ov); if (v >= 0) s->prm.mw_max = (int32_t)(v > (1L << 30) ? (1L << 30) : v); }
@@ -119,17 +125,31 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         (void)hipFree(s->state); if (s->start_tab) (void)hipFree(s->start_tab); delete s;
         return fail(SO100_E_NOMEM, "so100_create: start table upload failed%s");
     }
+    {   // workgroup load balancing of the persistent rollout kernel (pad-contact variants, batches it serves; SO100_BALANCE=0 turns it off)
+        const char* bal = getenv("SO100_BALANCE");
+        const bool pads = (cfg->flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE)) != 0;
+        if (pads && cfg->num_envs <= BALANCE_MAX_ENVS && !(bal && atoi(bal) == 0)) {
+            const size_t slots = (size_t)((cfg->num_envs + s->prm.epw - 1)/s->prm.epw)*(size_t)s->prm.epw;
+            if (hipMalloc(&s->slot_env, slots*sizeof(int32_t)) != hipSuccess) {
+                (void)hipFree(s->state); (void)hipFree(s->start_tab); delete s;
+                return fail(SO100_E_NOMEM, "so100_create: hipMalloc of the slot map failed%s");
+            }
+        }
+    }
     const hipError_t he = DISPATCH_KIND(cfg->env_kind, init)(s->prm.n, s->state);
-    if (he != hipSuccess) { (void)hipFree(s->state); (void)hipFree(s->start_tab); delete s; return fail(SO100_E_LAUNCH, "so100_create: %s (HIP error %ld)", hipGetErrorString(he), (long)he); }
+    if (he != hipSuccess) { (void)hipFree(s->state); (void)hipFree(s->start_tab); if (s->slot_env) (void)hipFree(s->slot_env); delete s; return fail(SO100_E_LAUNCH, "so100_create: %s (HIP error %ld)", hipGetErrorString(he), (long)he); }
     *out = s;
     return 0;
 }
+
+int so100_envs_per_workgroup(const so100_sim* s) { return s ? s->prm.epw : SO100_E_INVALID; }
 
 void so100_destroy(so100_sim* s) {
     if (!s) return;
     DeviceGuard g(s->cfg.device);
     if (s->state) (void)hipFree(s->state);
     if (s->start_tab) (void)hipFree(s->start_tab);
+    if (s->slot_env) (void)hipFree(s->slot_env);
     delete s;
 }
 
@@ -188,6 +208,13 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
     if (!g.ok) return fail(SO100_E_NODEVICE, "so100_rollout: cannot select the device%s");
     PolicyWeights pw; memcpy(&pw, w, sizeof pw);
     RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev; ra.tobs_chunk = io->terminal_obs_chunk_dev;
+    ra.slot_env = s->slot_env;
+    if (s->slot_env) {                                       // deal the envs that ended the last chunk in pad contact out over the workgroups
+        const int nwg = (s->prm.n + s->prm.epw - 1)/s->prm.epw;
+        hipLaunchKernelGGL(so100_build_slot_map, dim3(1), dim3(BALANCE_THREADS), 0, (hipStream_t)stream, s->prm.n, s->prm.epw, nwg,
+                           reinterpret_cast<const int32_t*>(s->state + (size_t)SF_contact_stat*(size_t)s->prm.n), s->slot_env);
+        HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
+    }
     RolloutPtrs rp{ io->obs_dev, io->rew_dev, io->done_dev, io->trunc_dev, io->terminal_obs_dev, io->ep_return_dev, io->ep_length_dev };
     HIP_TRY(DISPATCH_KIND(s->cfg.env_kind, rollout)(s->prm, s->state, s->start_tab, rp, pw, ra, (hipStream_t)stream), SO100_E_LAUNCH);
     return 0;

@@ -21,7 +21,7 @@ F_NOPADS = F_FRICTIONLOSS | F_LIMITS | F_FLOOR                         # round-1
 F_CONTACT5 = F_REFERENCE | F_PADS_CUBE                                  # BASELINE.json configs[4]: finger pads vs cube, coupled solve
 B_BAD_STATE = 128            # bit of the `bits` state row latched when a non-finite state ended an episode (csrc/so100_task.hpp)
 NINJECT = 16
-ABI_VERSION = 2              # include/so100_sim.h: SO100_ABI_VERSION
+ABI_VERSION = 3              # include/so100_sim.h: SO100_ABI_VERSION
 
 
 class So100Error(RuntimeError):
@@ -32,7 +32,7 @@ class Config(C.Structure):
     _fields_ = [("env_kind", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("flags", C.c_uint32),
                 ("solver_iters", C.c_int32), ("contact_iters", C.c_int32), ("frame_skip", C.c_int32),
                 ("max_episode_steps", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("envs_per_workgroup", C.c_uint32)]
 
 
 class StepIO(C.Structure):
@@ -65,7 +65,7 @@ class PolicyIO(C.Structure):
 
 
 EXPORTS = ["so100_abi_version", "so100_obs_dim", "so100_num_state_fields", "so100_state_field_index", "so100_state_field_name", "so100_create",
-           "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
+           "so100_envs_per_workgroup", "so100_destroy", "so100_reset", "so100_step", "so100_get_state", "so100_set_state", "so100_get_field",
            "so100_set_field", "so100_last_error", "so100_policy_forward", "so100_rollout"]
 
 
@@ -94,6 +94,7 @@ def load():
         L.so100_state_field_index.argtypes = [C.c_char_p]
         L.so100_state_field_name.argtypes = [C.c_int32]; L.so100_state_field_name.restype = C.c_char_p
         L.so100_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.so100_envs_per_workgroup.argtypes = [C.c_void_p]
         L.so100_destroy.argtypes = [C.c_void_p]
         L.so100_destroy.restype = None
         L.so100_reset.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -136,7 +137,7 @@ class So100Sim:
     """One batched simulator handle on one GPU (one per process per device)."""
 
     def __init__(self, env_kind, num_envs, device=None, flags=F_REFERENCE, solver_iters=2, contact_iters=20,
-                 frame_skip=16, max_episode_steps=None, seed=0, env_id_offset=0):
+                 frame_skip=16, max_episode_steps=None, seed=0, env_id_offset=0, envs_per_workgroup=0):
         self.L = load()
         if not torch.cuda.is_available():
             raise So100Error("no HIP device visible to PyTorch: so100 has no CPU fallback")
@@ -146,10 +147,11 @@ class So100Sim:
         if max_episode_steps is None:
             max_episode_steps = 4000 if env_kind == ENV01 else 6000       # ref: so100_mujoco_rl/__init__.py:5-45
         self.cfg = Config(env_kind, num_envs, self.device.index, flags, solver_iters, contact_iters, frame_skip,
-                          max_episode_steps, seed, env_id_offset, 0)
+                          max_episode_steps, seed, env_id_offset, envs_per_workgroup)
         h = C.c_void_p()
         _check(self.L.so100_create(C.byref(self.cfg), C.byref(h)), "so100_create")
         self.h = h
+        self.envs_per_workgroup = self.L.so100_envs_per_workgroup(h)     # in use (chosen by the library when 0 was passed): part of a checkpoint's configuration
         self.n = num_envs
         self.kind = env_kind
         self.obs_dim = self.L.so100_obs_dim(env_kind)
@@ -293,7 +295,7 @@ class So100Sim:
         c = self.cfg
         np.savez(path, words=words, names=np.array(names), obs=self.obs.cpu().numpy(),
                  config=np.array([c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip,
-                                  c.max_episode_steps, c.seed, c.env_id_offset], dtype=np.int64))
+                                  c.max_episode_steps, c.seed, c.env_id_offset, self.envs_per_workgroup], dtype=np.int64))
 
     def load_state(self, path, allow_config_mismatch=False):
         with np.load(path, allow_pickle=False) as z:
@@ -302,14 +304,22 @@ class So100Sim:
             raise So100Error(f"checkpoint is for env kind {int(conf[0])} x {int(conf[1])} envs, this sim is kind {self.cfg.env_kind} x {self.n}")
         # resume is bit exact only under the configuration the checkpoint was taken with: refuse anything else
         c = self.cfg
-        mine = [c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip, c.max_episode_steps, c.seed, c.env_id_offset]
-        labels = ["env_kind", "num_envs", "flags", "solver_iters", "contact_iters", "frame_skip", "max_episode_steps", "seed", "env_id_offset"]
+        mine = [c.env_kind, c.num_envs, c.flags, c.solver_iters, c.contact_iters, c.frame_skip, c.max_episode_steps, c.seed, c.env_id_offset,
+                self.envs_per_workgroup]
+        labels = ["env_kind", "num_envs", "flags", "solver_iters", "contact_iters", "frame_skip", "max_episode_steps", "seed", "env_id_offset",
+                  "envs_per_workgroup"]
+        # (envs_per_workgroup follows from N and the device's CU count unless pinned: the pad-contact solve's summation order depends on it,
+        #  so a resume is bit exact only under the same value; checkpoints of earlier versions do not carry it)
         diff = [f"{l}: checkpoint {int(a)} != sim {int(b)}" for l, a, b in zip(labels, conf, mine) if int(a) != int(b)]
+        if len(conf) < len(mine):
+            diff.append("envs_per_workgroup: not recorded in this (older) checkpoint")
         if diff and not allow_config_mismatch:
             raise So100Error("checkpoint was taken under a different configuration (" + "; ".join(diff) + "); pass allow_config_mismatch=True to load it anyway")
         missing = set(self.field_names()) - set(names)
-        if missing:
-            raise So100Error(f"checkpoint lacks state fields {sorted(missing)}")
+        if missing and not allow_config_mismatch:
+            raise So100Error(f"checkpoint lacks state fields {sorted(missing)} (written by an older version?); allow_config_mismatch=True zero-fills them")
+        for n in sorted(missing):                           # older checkpoint, loaded on request: solver memory / statistics rows start from zero
+            self.set_field(n, torch.zeros(self.n, dtype=torch.int32, device=self.device))
         for row, n in zip(words, names):
             if self.L.so100_state_field_index(n.encode()) >= 0:
                 self.set_field(n, torch.from_numpy(row).to(self.device))

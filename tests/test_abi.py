@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(L):
 
 
 def test_metadata_calls(L):
-    assert L.so100_abi_version() == 2
+    assert L.so100_abi_version() == 3
     assert [L.so100_obs_dim(k) for k in (1, 2, 3, 4, 5, 6)] == [15, 15, 8, 8, 8, 15]
     assert L.so100_obs_dim(0) == -1 and L.so100_obs_dim(7) == -1
     n = L.so100_num_state_fields()

@@ -112,7 +112,7 @@ def test_contact5_determinism_and_shard_invariance_4096():
     act = act + rs.uniform(-0.3, 0.3, act.shape).astype(np.float32); act[:, 5] = -1.0
 
     def run(n_envs, off, sl):
-        sim = So100Sim(2, n_envs, flags=C5, seed=9, env_id_offset=off, max_episode_steps=0)
+        sim = So100Sim(1, n_envs, flags=C5, seed=9, env_id_offset=off, max_episode_steps=0)     # (Env02 would re-randomise the cube on its first step: Q1)
         sim.reset()
         sim.set_state(torch.from_numpy(np.ascontiguousarray(qpos[sl].T, np.float32)).cuda(), torch.from_numpy(np.ascontiguousarray(qvel[sl].T, np.float32)).cuda())
         a = torch.from_numpy(np.ascontiguousarray(act[sl])).cuda(); coupled = 0
@@ -129,3 +129,35 @@ def test_contact5_determinism_and_shard_invariance_4096():
     lo, qa, va, _ = run(n//2, 0, slice(0, n//2)); hi, qb, vb, _ = run(n//2, n//2, slice(n//2, n))
     assert torch.equal(torch.cat([lo, hi], 0), full) and torch.equal(torch.cat([qa, qb], 1), q) and torch.equal(torch.cat([va, vb], 1), v)
     assert torch.isfinite(full).all() and coupled >= 8       # face-face manifolds on both sides of the cube
+
+
+def test_workgroup_balancing_leaves_every_result_bit_identical():
+    """so100_rollout deals the envs that ended the previous chunk in pad contact out over the workgroups (csrc/so100_balance.hpp): which
+    lane computes an env must not change a single bit of its results.  Half of the batch starts on the table, half parked in the air, so
+    the map differs from the identity; three chunks, TimeLimit resets inside."""
+    import os
+    from so100_mujoco_rl_amd.vec_env import So100VecEnv
+    from so100_mujoco_rl_amd.collector import RolloutCollector
+    n, T = 1000, 6                                           # 63 workgroups of 16 envs, the last one partially filled
+    qpos, qvel = _contact_rich_state(n, REFP, 3)
+    qpos[::2, :6] = [0.0, -1.9, 1.6, 0.3, 1.5708, 0.1]; qvel[::2] = 0.0      # every other arm folded up 28 cm above the table
+    outs = []
+    for bal in ("1", "0"):
+        os.environ["SO100_BALANCE"] = bal
+        try:
+            env = So100VecEnv(1, n, flags=REFP, seed=8, max_episode_steps=11)
+        finally:
+            del os.environ["SO100_BALANCE"]
+        sd = RolloutCollector.random_policy_state(15, env.device, seed=5); sd["action_net.bias"][1] = 0.4
+        col = RolloutCollector(env, sd, T=T, persistent=True, bootstrap_truncated=False)
+        _start(env, col, qpos, qvel, 1)
+        chunks = [{k: v.clone() for k, v in col.collect().items()} for _ in range(3)]
+        q, v = env.sim.get_state()
+        outs.append((chunks, q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone(), env.sim.ep_length.clone()))
+        env.close()
+    (ca, qa, va, csa, la), (cb, qb, vb, csb, lb) = outs
+    assert ((csa & 255) > 0).float().mean() > 0.1            # the contact path ran, so the map was not the identity
+    for a, b in zip(ca, cb):
+        for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(csa, csb) and torch.equal(la, lb)

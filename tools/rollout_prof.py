@@ -39,9 +39,13 @@ if mode == "held":                          # a constant lifting action on the s
     sd["action_net.bias"][1] = -1.0
 sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
 buf = torch.empty(T, n, sim.obs_dim + 10, device="cuda")
+hist = (C.c_ulonglong * 48)()
 for i in range(4):
+    if i == 3:
+        torch.cuda.synchronize(); sim.L.so100_prof_read_hist(1, hist, 1)          # statistics of the last launch only
     sim.rollout(buf, i * T)
 torch.cuda.synchronize()
+sim.L.so100_prof_read_hist(1, hist, 0)
 out = (C.c_longlong * 48)()
 assert sim.L.so100_prof_read(1, out) == 0
 names = ["policy layers (MFMA+tanh, 2 barriers)", "head+noise+row+env_step_pre", "trig + publish", "barrier-1 wait",
@@ -75,3 +79,13 @@ if sim.L.so100_prof_read_wg(1, wg, envw) == 0:
     insub = E[:, 1].sum(); work = E[:, 0].sum()
     print(f"# all envs: {100.0*insub/(n*T*16):.1f} % of env-substeps in pad contact, {work/max(insub,1):.2f} row passes per contact substep; per-wg sum over envs of row passes: median {np.median(E[:,0].reshape(nwg, epw).sum(1)):.0f} max {E[:,0].reshape(nwg, epw).sum(1).max():.0f};"
           f" per-wg MAX-lane passes: median {np.median(E[:,0].reshape(nwg, epw).max(1)):.0f} max {E[:,0].reshape(nwg, epw).max(1).max():.0f}")
+
+h = list(hist)
+if h[39]:
+    print(f"# contact Newton per (workgroup, substep) of the last launch: {h[39]} pairs, {100.0*h[38]/h[39]:.1f} % with a solve; envs solving at once: "
+          + " ".join(f"{k}:{100.0*h[16+k]/h[39]:.1f}%" for k in range(17) if h[16+k]))
+    if h[38]:
+        print("#   slowest lane's gradient+Hessian passes: " + " ".join(f"{k}:{100.0*h[k]/h[38]:.1f}%" for k in range(16) if h[k])
+              + f";  its estimated instructions: mean {h[37]/h[38]:.0f} (all solving envs: mean {h[40]/max(1, h[33] and sum(h[16+k]*k for k in range(17))):.0f})")
+        ns = max(1, sum(h[16+k]*k for k in range(17)))
+        print(f"#   passes per solve (all envs): full {h[33]/ns:.2f}  sign {h[34]/ns:.2f}  gradient {h[35]/ns:.2f}  line-search {h[36]/ns:.2f}")
