@@ -413,6 +413,24 @@ SO100_HD int box_box(const T cA[3], const T RA[9], const T hA[3], const T cB[3],
     return cnt;
 }
 
+// The box (in jaw coordinates) that encloses all pads of one jaw link: centre and half sizes, compile-time from the pad table.
+SO100_HD constexpr double pad_hull_lo(int link, int ax) {
+    double lo = 1e30;
+    for (int g = 0; g < so100g::NPAD; g++) if (so100g::PAD_LINK[g] == link) { const double v = so100g::PAD_POS[g][ax] - so100g::PAD_SIZE[g][ax]; lo = v < lo ? v : lo; }
+    return lo;
+}
+SO100_HD constexpr double pad_hull_hi(int link, int ax) {
+    double hi = -1e30;
+    for (int g = 0; g < so100g::NPAD; g++) if (so100g::PAD_LINK[g] == link) { const double v = so100g::PAD_POS[g][ax] + so100g::PAD_SIZE[g][ax]; hi = v > hi ? v : hi; }
+    return hi;
+}
+// lowest point (world z) of that box for a jaw at origin o with rotation R (row-major, world <- jaw): no pad of the jaw reaches lower
+template <int LINK, typename T> SO100_HD T pad_hull_lowest(const T o[3], const T R[9]) {
+    constexpr double cx = 0.5*(pad_hull_lo(LINK, 0) + pad_hull_hi(LINK, 0)), cy = 0.5*(pad_hull_lo(LINK, 1) + pad_hull_hi(LINK, 1)), cz = 0.5*(pad_hull_lo(LINK, 2) + pad_hull_hi(LINK, 2));
+    constexpr double hx = 0.5*(pad_hull_hi(LINK, 0) - pad_hull_lo(LINK, 0)), hy = 0.5*(pad_hull_hi(LINK, 1) - pad_hull_lo(LINK, 1)), hz = 0.5*(pad_hull_hi(LINK, 2) - pad_hull_lo(LINK, 2));
+    return o[2] + (R[6]*T(cx) + R[7]*T(cy) + R[8]*T(cz)) - (tabs(R[6])*T(hx) + tabs(R[7])*T(hy) + tabs(R[8])*T(hz)) - T(1e-6);     // (1e-6 m: fp32 round-off of this bound vs the per-pad test)
+}
+
 // ---- detection: fills the contact store for one env --------------------------------------------------------------------
 // v = q-dot of the arm, cube pose / velocity; W = world FK of this substep.  Store order: pad/floor by pad, pad/cube by pad
 // (these two share the budget MAXPADC), then -- only when a pad touches the cube, i.e. arm and cube must be solved together --
@@ -438,7 +456,10 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             dc2 = tmin(dc2, dx*dx + dy*dy + dz*dz);
         }
     }
-    const bool near_floor = (flags & F_PADS_FLOOR) != 0u && zmin < T(PAD_REACH);
+    // pad/floor: the box around each jaw's pads against the plane -- exact for the box, so a jaw hovering a millimetre over the table does not
+    // send its wave into the per-pad tests (the old bound, zmin < PAD_REACH, let every arm within 11 cm of the table through)
+    const bool near_floor = (flags & F_PADS_FLOOR) != 0u && zmin < T(PAD_REACH)
+                            && tmin(pad_hull_lowest<4, T>(W.o[4], W.R4), pad_hull_lowest<5, T>(W.o[5], W.R5)) <= T(0);
     const bool near_cube = dc2 < T((PAD_REACH + so100g::CUBE_HALF*1.7320508075688772)*(PAD_REACH + so100g::CUBE_HALF*1.7320508075688772));
     auto pad_frame = [&](int g, T R[9], T o[3], T h[3], T c[3]) {
         const bool l5 = so100g::PAD_LINK[g] == 5;

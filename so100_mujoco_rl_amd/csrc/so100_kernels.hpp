@@ -116,6 +116,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     __shared__ float xk[PADS ? 12 : 1][64];
     __shared__ float xm[PADS ? 21 : 1][64];
     __shared__ unsigned char pbuf[PADS ? MAXC*64 : 1];
+    __shared__ float xw[PADS ? 36 : 1][64];                       // joint axes / screw terms, contact wave's detection -> its solve
     if (FL >= 0) p.flags = (unsigned)FL;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -134,7 +135,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
         env_step_pre<KIND>(e, a, u, p, ctx);
     }
     Arm<float> A; Prof prof_;
-    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm, pbuf };
+    const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm, pbuf, PADS ? xw : nullptr };
     ContactMemo memo;                                             // (reset by physics_phase_mw: the memory lives for the env step's substeps)
     physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [](int) {}, [&]() {
         ctx = StepCtx{};

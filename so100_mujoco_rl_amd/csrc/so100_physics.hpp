@@ -543,6 +543,22 @@ SO100_HD void arm_row_consts(const T q[6], const T v[6], unsigned flags, ArmRows
         r.Dl[i] = act ? trcp(r.Rl[i]) : T(0);
     }
 }
+// the same constants for a primal solve on ANOTHER wave, from what the wave that holds q published: sD[i] = sg_i / R_limit,i (0 = limit row
+// inactive) and clv (physics_phase_mw: wave 1 prepares them behind RNEA, the contact wave reads 12 words instead of redoing ~150 instructions)
+template <typename T>
+SO100_HD void arm_row_consts_from(const T v[6], unsigned flags, const T sD[6], const T clv[6], ArmRows<T>& r) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        r.Rf[i] = T((1.0 - so100g::SOLIMP_D0)/so100g::SOLIMP_D0 * so100g::DOF_INVWEIGHT0[i]);
+        r.cfv[i] = T(so100g::SOLREF_B)*v[i];
+        r.fmax_[i] = (flags & F_FRICTIONLOSS) != 0u ? T(so100g::FRICTIONLOSS) : T(0);
+        r.Df[i] = (flags & F_FRICTIONLOSS) != 0u ? T(so100g::SOLIMP_D0/((1.0 - so100g::SOLIMP_D0)*so100g::DOF_INVWEIGHT0[i])) : T(0);
+        r.sg[i] = sD[i] > T(0) ? T(1) : (sD[i] < T(0) ? T(-1) : T(0));
+        r.Dl[i] = tabs(sD[i]);
+        r.clv[i] = clv[i];
+        r.Rl[i] = T(0);                                      // (not used by the primal solve)
+    }
+}
 // friction-loss / limit row forces that go with a given acceleration (the block PGS's warm-start memory after a primal solve)
 template <typename T>
 SO100_HD void arm_row_forces(const ArmRows<T>& r, const T acc[6], T ff[6], T fl[6]) {

@@ -114,9 +114,13 @@ struct Prof {
 // LDS: xq [24][64] = sin q, cos q, v, q; xk [12][64] = ctrl (written once per env step) and the arm's acceleration of the
 // previous substep (6-11: the Newton's warm start, republished by wave 0 after every substep); xa [15][64] = arm
 // acceleration (0-5) and cube acceleration (6-11) of the contact wave's solve, contact code (12: count | coupled << 8 |
-// dropped << 16), solver residual (13), signature of the pad-contact set (14).
+// dropped << 16), solver residual (13), signature of the pad-contact set (14).  During the FIRST half of a substep rows 0-11 of xa and the
+// q rows of xq (18-23) carry, from wave 1 to the contact wave, the arm's smooth force tau (xa 0-5), the limit rows' constants clv (xa 6-11) and
+// sg / R_limit (xq 18-23): wave 1 forms them behind RNEA (it is the short leg of that half), the contact wave then needs no q, ctrl or bias.
 // xm [21][64] = the arm's mass matrix (packed lower, unfactored), published by wave 0 before it factorises it in place.
-struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; unsigned char* pbuf; };
+// xw [36][64] (nullable) = the six joint axes z_k and screw terms o_k x z_k in the world frame (all the solve needs of the world FK), from the
+// contact wave's detection to its solve; without it the solve rebuilds the frames from sin / cos (330 instructions per substep in contact).
+struct PhaseLds { float (*xq)[64]; float (*xc)[64]; float (*xb)[64]; float* cbuf; float (*xa)[64]; float (*xk)[64]; float (*xm)[64]; unsigned char* pbuf; float (*xw)[64]; };
 // the contact wave's active-set memory (so100_contact.hpp: primal_newton) lives for ONE env step, like the one-wave kernel's
 // (physics_substeps): zones = the arm rows' zones of the last contact solve (-1: none yet), prev_n = length of the (id | mask) list in L.pbuf
 struct ContactMemo { int zones = -1, prev_n = 0; };
@@ -209,12 +213,23 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         float Rc3[9] = { 1.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f, 0.0f, 1.0f }, cpos3[3] = { 0.0f, 0.0f, 0.0f };
         bool coupled3 = false, any3 = false;
         if (wave == 1) {
-            float v1[6];
+            float v1[6], q1[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, c1[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
             for (int i = 0; i < 6; i++) { A.s[i] = xq[i][lane]; A.c[i] = xq[6 + i][lane]; v1[i] = xq[12 + i][lane]; }
+            if (pads) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) { q1[i] = xq[18 + i][lane]; c1[i] = xk[i][lane]; }
+            }
             arm_bias<float>(v1, A);
 #pragma unroll
             for (int i = 0; i < 6; i++) xb[i][lane] = A.bias[i];
+            if (pads) {                                    // what the contact wave's primal solve needs of q, ctrl and the bias (see "LDS" above)
+                float t1[6]; ArmRows<float> r1;
+                arm_tau<float>(q1, v1, c1, A, t1);
+                arm_row_consts<float>(q1, v1, p.flags, r1);
+#pragma unroll
+                for (int i = 0; i < 6; i++) { xa[i][lane] = t1[i]; xa[6 + i][lane] = r1.clv[i]; xq[18 + i][lane] = r1.sg[i]*r1.Dl[i]; }
+            }
             SO100_PROF(4);                                 // RNEA (wave 1)
         } else if (wave == 0) {
             arm_mass<float>(A);
@@ -251,6 +266,12 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
             if (part3 == 0) xa[12][el] = __int_as_float(cs3.n | (coupled3 ? 256 : 0) | ((cs3.dropped > 0xFFFF ? 0xFFFF : cs3.dropped) << 16));
             any3 = __any(cs3.n > 0);
             if (any3) { const int sig3 = cs3.n > 0 ? contact_signature(cs3) : 0; if (part3 == 0) xa[14][el] = __int_as_float(sig3); }
+            if (L.xw && cs3.n > 0 && part3 == 0) {         // the joint frames for the solve after the barrier
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { L.xw[3*i + k][el] = W3.z[i][k]; L.xw[18 + 3*i + k][el] = W3.oz[i][k]; }
+            }
             SO100_PROF(4);                                 // FK + narrowphase (wave 3)
         }
         __syncthreads();
@@ -278,13 +299,20 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
         }
         if (wave == 3 && pads && any3) {
             if (cs3.n > 0) {
-                float q3[6], v3[6], c3[6], tau3[6], x3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
-                // the joint frames again, from the published sin / cos (270 instructions, only in waves that have a contact): keeping
-                // the 72 floats of the detection's copy alive across the barrier costs every wave's code registers (one allocation for
-                // the whole kernel) and showed up as scratch traffic in the arm / cube legs
+                float v3[6], tau3[6], x3[6], sD3[6], clv3[6], xcube[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f }, cwarm[6], ap3[3] = { 0.0f, 0.0f, 0.0f };
+                // The joint axes / screw terms: from LDS where the kernel has room for them, else rebuilt from the published sin / cos (330
+                // instructions).  Keeping the detection's copy in registers across the barrier is not an option: one register allocation
+                // serves the whole kernel, and the 72 floats showed up as scratch traffic in the arm / cube legs.
+                if (L.xw) {
 #pragma unroll
-                for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][el]; A3.c[i] = xq[6 + i][el]; }
-                world_fk<float>(A3.s, A3.c, W3);
+                    for (int i = 0; i < 6; i++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) { W3.z[i][k] = L.xw[3*i + k][el]; W3.oz[i][k] = L.xw[18 + 3*i + k][el]; }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][el]; A3.c[i] = xq[6 + i][el]; }
+                    world_fk<float>(A3.s, A3.c, W3);
+                }
                 if (padcube) {
 #pragma unroll
                     for (int i = 0; i < 3; i++) cpos3[i] = xc[i][el];
@@ -294,10 +322,9 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
 #pragma unroll
                 for (int i = 0; i < 21; i++) A3.M[i] = xm[i][el];
 #pragma unroll
-                for (int i = 0; i < 6; i++) { q3[i] = xq[18 + i][el]; v3[i] = xq[12 + i][el]; c3[i] = xk[i][el]; A3.bias[i] = xb[i][el]; x3[i] = xk[6 + i][el]; cwarm[i] = 0.0f; }
-                arm_tau<float>(q3, v3, c3, A3, tau3);
+                for (int i = 0; i < 6; i++) { v3[i] = xq[12 + i][el]; tau3[i] = xa[i][el]; clv3[i] = xa[6 + i][el]; sD3[i] = xq[18 + i][el]; x3[i] = xk[6 + i][el]; cwarm[i] = 0.0f; }
                 ArmRows<float> r3;
-                arm_row_consts<float>(q3, v3, p.flags, r3);
+                arm_row_consts_from<float>(v3, p.flags, sD3, clv3, r3);
                 if (coupled3) {
 #pragma unroll
                     for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][el];
@@ -534,6 +561,11 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     float (*xmean)[64] = reinterpret_cast<float (*)[64]>(pool + HB);   // action means, two per wave (waves 0, 1, 3 -> wave 0)
     float (*xm)[64] = reinterpret_cast<float (*)[64]>(pool + MAXC*CF*64);
     static_assert(HB + 6*64 >= MAXC*CF*64 + 21*64, "contact records + mass matrix must fit under the policy phase's images");
+    // Without pad/cube contacts (compile-time flags) the store never holds more than the MAXPADC pad/floor records: its tail carries the joint
+    // frames from the contact wave's detection to its solve.  (Variants with F_PADS_CUBE have no room left: they rebuild the frames.)
+    constexpr bool XW = FL >= 0 && (FL & (int)F_PADS_CUBE) == 0 && (FL & (int)F_PADS_FLOOR) != 0;
+    static_assert(!XW || MAXPADC*CF*64 + 36*64 <= MAXC*CF*64, "joint frames must fit in the unused tail of the contact store");
+    float (*xw)[64] = XW ? reinterpret_cast<float (*)[64]>(pool + MAXPADC*CF*64) : nullptr;
     constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
     __shared__ float xa[PADS ? 15 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual, set signature
     __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
@@ -687,7 +719,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         //      lanes with pad contacts to the solver tolerance (same warm start and active-set memory, differently rounded inputs).
         {
             Arm<float> A;
-                        const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm, pbuf };
+                        const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm, pbuf, xw };
             physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];

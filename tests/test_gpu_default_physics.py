@@ -151,9 +151,13 @@ def test_workgroup_balancing_leaves_every_result_bit_identical():
         sd = RolloutCollector.random_policy_state(15, env.device, seed=5); sd["action_net.bias"][1] = 0.4
         col = RolloutCollector(env, sd, T=T, persistent=True, bootstrap_truncated=False)
         _start(env, col, qpos, qvel, 1)
-        chunks = [{k: v.clone() for k, v in col.collect().items()} for _ in range(3)]
+        chunks = []
+        for c in range(3):
+            chunks.append({k: v.clone() for k, v in col.collect().items()})
+            if c == 0:                                       # (contact_stat at the end of a chunk is what the next launch's map is dealt from)
+                cs = env.sim.get_field("contact_stat", dtype=torch.int32).clone()
         q, v = env.sim.get_state()
-        outs.append((chunks, q.clone(), v.clone(), env.sim.get_field("contact_stat", dtype=torch.int32).clone(), env.sim.ep_length.clone()))
+        outs.append((chunks, q.clone(), v.clone(), cs, env.sim.ep_length.clone()))
         env.close()
     (ca, qa, va, csa, la), (cb, qb, vb, csb, lb) = outs
     assert ((csa & 255) > 0).float().mean() > 0.1            # the contact path ran, so the map was not the identity

@@ -40,9 +40,16 @@ if mode == "held":                          # a constant lifting action on the s
 sim.set_policy({k: sd[SB3_STATE_DICT_KEYS[k]].contiguous() for k in POLICY_TENSORS})
 buf = torch.empty(T, n, sim.obs_dim + 10, device="cuda")
 hist = (C.c_ulonglong * 48)()
+import numpy as np
+sim.L.so100_prof_read_wg.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+prev_env = None; busy_at_start = None
 for i in range(4):
     if i == 3:
         torch.cuda.synchronize(); sim.L.so100_prof_read_hist(1, hist, 1)          # statistics of the last launch only
+        _wg = (C.c_longlong * 4096)(); _ev = (C.c_int * 32768)()
+        if sim.L.so100_prof_read_wg(1, _wg, _ev) == 0:
+            prev_env = np.array(_ev[:2*n]).reshape(n, 2).copy()                   # per slot: passes, substeps in contact of launch 2
+        busy_at_start = ((sim.get_field("contact_stat", dtype=torch.int32) & 255) > 0).cpu().numpy()
     sim.rollout(buf, i * T)
 torch.cuda.synchronize()
 sim.L.so100_prof_read_hist(1, hist, 0)
@@ -80,6 +87,10 @@ if sim.L.so100_prof_read_wg(1, wg, envw) == 0:
     print(f"# all envs: {100.0*insub/(n*T*16):.1f} % of env-substeps in pad contact, {work/max(insub,1):.2f} row passes per contact substep; per-wg sum over envs of row passes: median {np.median(E[:,0].reshape(nwg, epw).sum(1)):.0f} max {E[:,0].reshape(nwg, epw).sum(1).max():.0f};"
           f" per-wg MAX-lane passes: median {np.median(E[:,0].reshape(nwg, epw).max(1)):.0f} max {E[:,0].reshape(nwg, epw).max(1).max():.0f}")
 
+if prev_env is not None and os.environ.get("SO100_BALANCE") == "0":        # (identity slot map: slot == env, so launches can be compared env by env)
+    a = prev_env[:, 1].astype(float); b = E[:, 1].astype(float)
+    print(f"# contact substeps per env, launch 2 vs launch 3: correlation {np.corrcoef(a, b)[0, 1]:.3f}; envs in contact at the start of launch 3 ({busy_at_start.mean():.3f} of all) "
+          f"carry {b[busy_at_start].sum()/max(b.sum(), 1):.3f} of its contact substeps; the top quarter of launch 2 carries {b[np.argsort(-a)[:n//4]].sum()/max(b.sum(), 1):.3f}")
 h = list(hist)
 if h[39]:
     print(f"# contact Newton per (workgroup, substep) of the last launch: {h[39]} pairs, {100.0*h[38]/h[39]:.1f} % with a solve; envs solving at once: "
