@@ -158,6 +158,27 @@ void so100o_model_init(so100o_model* m) {
     m->def_solimp[3] = SO100_SOLIMP_MID; m->def_solimp[4] = SO100_SOLIMP_POWER;
     m->def_friction = SO100_GEOM_FRICTION;
     m->max_contacts = 16;                            /* the product's contact budget per env (csrc/so100_contact.hpp) */
+    /* link proxies (stand-in capsules for the absent collision meshes; rule: so100_model_def.h) */
+    for (int k = 0; k < SO100_NPROX; k++) {
+        const int l = SO100_PROX_LINK[k], b = l + 2;
+        m->prox_body[k] = b;
+        memset(m->prox_p[k], 0, sizeof m->prox_p[k]);
+        if (l <= 3) memcpy(m->prox_p[k][1], SO100_LINK_POS[l + 1], sizeof(double)*3);
+        else {
+            double xlo = 1e30, xhi = -1e30, ymax = 0;
+            for (int g = 0; g < SO100_NPAD; g++) if (SO100_PAD_LINK[g] == l) {
+                xlo = fmin(xlo, SO100_PAD_POS[g][0] - SO100_PAD_SIZE[g][0]); xhi = fmax(xhi, SO100_PAD_POS[g][0] + SO100_PAD_SIZE[g][0]);
+                if (fabs(SO100_PAD_POS[g][1]) + SO100_PAD_SIZE[g][1] > fabs(ymax)) ymax = SO100_PAD_POS[g][1] < 0 ? SO100_PAD_POS[g][1] - SO100_PAD_SIZE[g][1] : SO100_PAD_POS[g][1] + SO100_PAD_SIZE[g][1];
+            }
+            m->prox_p[k][1][0] = 0.5*(xlo + xhi); m->prox_p[k][1][1] = ymax; m->prox_p[k][1][2] = 0.0;
+        }
+        const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+        double h[3] = { 0.5*sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
+        const double hmax = fmax(h[0], fmax(h[1], h[2]));
+        double r = 0.5*(h[0] + h[1] + h[2] - hmax);
+        if (l >= 4 && r > SO100_PROX_JAW_RADIUS_MAX) r = SO100_PROX_JAW_RADIUS_MAX;
+        m->prox_radius[k] = r;
+    }
 
     /* mj_setConst: dof_M0, dof_invweight0, body_invweight0 at qpos0, then kv from dampratio */
     so100o_data* d = (so100o_data*)calloc(1, sizeof *d);
@@ -729,6 +750,23 @@ static void make_constraints(const so100o_model* m, so100o_data* d, unsigned fla
             for (int k = 0; k < 3; k++) c[k] = d->xpos[b][k] + v[k];
             const int n = so100o_box_box(c, d->xmat[b], m->pad_size[g], d->xpos[CUBE], d->xmat[CUBE], hs, pos, nrm, dist);
             for (int k = 0; k < n; k++) add_contact(m, d, 2, g, 64 + 8*g + k, b, CUBE, pos[k], nrm, dist[k], mu, ref, imp);
+        }
+    }
+    if (flags & SO100O_F_LINKS_FLOOR) {                     /* (after the pad pairs: the order the product's contact store is filled in) */
+        /* mjc_PlaneCapsule: a plane-sphere test at either end of the segment; contact point midway between the sphere's lowest point and the plane */
+        double ref[2], imp[5], mu;
+        mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->def_solref, m->def_solimp, m->def_friction, ref, imp, &mu);
+        for (int k = 0; k < SO100O_NPROX; k++) {
+            const int b = m->prox_body[k];
+            for (int e = 0; e < 2; e++) {
+                double c[3], v[3];
+                mat_vec3(v, d->xmat[b], m->prox_p[k][e]);
+                for (int a = 0; a < 3; a++) c[a] = d->xpos[b][a] + v[a];
+                const double dist = c[2] - m->prox_radius[k];
+                if (dist > 0) continue;
+                const double pos[3] = { c[0], c[1], c[2] - m->prox_radius[k] - 0.5*dist };
+                add_contact(m, d, 3, k, 144 + 2*k + e, 0, b, pos, nz, dist, mu, ref, imp);
+            }
         }
     }
 }

@@ -190,6 +190,32 @@ int main(int argc, char** argv) {
     emit(f, "PAD_SIZE", &SO100_PAD_SIZE[0][0], SO100_NPAD, 3);
     emit1(f, "LINK_INVWEIGHT_TRAN", INVW_TRAN, N);
     std::fprintf(f, "static constexpr double PADC_K = %.17g, PADC_B = %.17g, PADC_D0 = %.17g, PADC_DMAX = %.17g, PADC_WIDTH = %.17g, PADC_MU = %.17g;\n", PK, PB, pd0, pdm, pw, pmu);
+    {   // link proxies (stand-in capsules for the absent collision meshes): the rule of so100_model_def.h, as in oracle/so100_oracle.c
+        double far_[SO100_NPROX][3] = {{0}}, rad[SO100_NPROX];
+        for (int k = 0; k < SO100_NPROX; k++) {
+            const int l = SO100_PROX_LINK[k];
+            if (l <= 3) for (int a = 0; a < 3; a++) far_[k][a] = SO100_LINK_POS[l + 1][a];
+            else {
+                double xlo = 1e30, xhi = -1e30, ymax = 0;
+                for (int g = 0; g < SO100_NPAD; g++) if (SO100_PAD_LINK[g] == l) {
+                    xlo = std::fmin(xlo, SO100_PAD_POS[g][0] - SO100_PAD_SIZE[g][0]); xhi = std::fmax(xhi, SO100_PAD_POS[g][0] + SO100_PAD_SIZE[g][0]);
+                    if (std::fabs(SO100_PAD_POS[g][1]) + SO100_PAD_SIZE[g][1] > std::fabs(ymax))
+                        ymax = SO100_PAD_POS[g][1] < 0 ? SO100_PAD_POS[g][1] - SO100_PAD_SIZE[g][1] : SO100_PAD_POS[g][1] + SO100_PAD_SIZE[g][1];
+                }
+                far_[k][0] = 0.5*(xlo + xhi); far_[k][1] = ymax; far_[k][2] = 0.0;
+            }
+            const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+            const double h[3] = { 0.5*std::sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*std::sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*std::sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
+            const double hmax = std::fmax(h[0], std::fmax(h[1], h[2]));
+            rad[k] = 0.5*(h[0] + h[1] + h[2] - hmax);
+            if (l >= 4 && rad[k] > SO100_PROX_JAW_RADIUS_MAX) rad[k] = SO100_PROX_JAW_RADIUS_MAX;
+        }
+        std::fprintf(f, "// link proxies (F_LINKS_FLOOR): capsule k on link k + 1, from that link's joint origin to PROX_FAR[k] -- for links 1-3 the child's joint origin -- in link coordinates\n");
+        std::fprintf(f, "static constexpr int NPROX = %d;\n", SO100_NPROX);
+        std::fprintf(f, "static constexpr int PROX_LINK[%d] = { %d, %d, %d, %d, %d };\n", SO100_NPROX, SO100_PROX_LINK[0], SO100_PROX_LINK[1], SO100_PROX_LINK[2], SO100_PROX_LINK[3], SO100_PROX_LINK[4]);
+        emit(f, "PROX_FAR", &far_[0][0], SO100_NPROX, 3);
+        emit1(f, "PROX_RADIUS", rad, SO100_NPROX);
+    }
     std::fprintf(f, "}  // namespace so100g\n");
     std::fclose(f);
     return 0;

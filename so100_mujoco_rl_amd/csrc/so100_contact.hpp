@@ -34,12 +34,13 @@
 #define SO100_LEAN_DX 0.02     // size of a Newton step, SO100_LEAN_ABS + SO100_LEAN_DX |x| (rad/s^2), up to which its round-off is removed by
 #endif                         // refining the LINEAR system (see primal_newton: lean_refine)
 #ifndef SO100_LEAN_ABS
-#define SO100_LEAN_ABS 2.0
+#define SO100_LEAN_ABS 8.0
 #endif
 
 namespace so100 {
 
-enum : unsigned { F_PADS_FLOOR = 16u, F_PADS_CUBE = 32u };
+enum : unsigned { F_PADS_FLOOR = 16u, F_PADS_CUBE = 32u, F_LINKS_FLOOR = 64u };
+constexpr unsigned F_ANY_CONTACT = F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR;      // any of these: the contact store / contact wave / primal solve are in play
 
 constexpr int MAXPADC = 16;                  // budget of PAD contacts per env (oracle: model.max_contacts); detection order = pad/floor
                                              // by pad, then pad/cube by pad; further ones are dropped and counted
@@ -49,11 +50,14 @@ enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY,
 // C_P point (world, midway between the surfaces), C_N normal geom1 -> geom2 (the tangents follow from it: mju_makeFrame),
 // C_KD = K imp dist, C_RINV = 1/R of the 4 edge rows, C_V = B * relative point velocity (the velocity part of -aref),
 // C_KIND: kind | id << 3 | mask0 << 11 (an integer held in a float) -- kind: 0 cube/floor, 1 / 2 pad/floor on link 4 / 5, 3 / 4 pad/cube
-// with the pad on link 4 / 5; id: which geometric feature made the contact (pad corner, manifold slot: stable from substep to substep);
+// with the pad on link 4 / 5, 5 link proxy/floor (F_LINKS_FLOOR; id = 144 + 2 proxy + capsule end, on link proxy + 1); id: which geometric feature made the contact (pad corner, manifold slot: stable from substep to substep);
 // mask0: the pyramid edges that carried force at the end of the previous substep's solve (the Newton's first guess of the active set).
 // The solver leaves (hash(id) << 4 | final mask), one byte, of every record in the store's "previous" list for the next substep's
 // detection (4-bit hash: distinct for the same corner of different pads; a collision only costs a worse first guess).
 SO100_HD int contact_id_hash(int id) { return (id ^ (id >> 4)) & 15; }
+// the arm link (0..5) that carries the record's arm-side geom (kind != 0)
+static_assert(so100g::NPROX == 5 && so100g::PROX_LINK[0] == 1 && so100g::PROX_LINK[4] == 5, "proxy k sits on link k + 1");
+SO100_HD int contact_link(int kind, int id) { return kind == 5 ? ((id - 144) >> 1) + 1 : ((kind == 2 || kind == 4) ? 5 : 4); }
 // 32-bit mix of a feature id; a contact SET's signature is the wrapping sum of it over the set's PAD contacts (order-free: the
 // cooperating lanes add their shares).  Parity tests compare it with the same sum over the oracle's contact list (so100o_contact.feat).
 SO100_HD int contact_id_mix(int id) {
@@ -103,7 +107,7 @@ template <class Store> SO100_HD int coop_or(const Store& cs, int v) {
 
 template <typename T> struct ContactsPriv {                 // one env's records in a private array
     static constexpr bool COOP = false; static constexpr int part = 0, nparts = 1;
-    T a[MAXC*CF]; int n = 0, dropped = 0;
+    T a[MAXC*CF]; int n = 0, dropped = 0, sig = 0;
     unsigned char pcode[MAXC]; int prev_n = 0;
     SO100_HD T get(int s, int f) const { return a[s*CF + f]; }
     SO100_HD void set(int s, int f, T v) { a[s*CF + f] = v; }
@@ -113,7 +117,7 @@ template <typename T> struct ContactsPriv {                 // one env's records
 template <typename T> struct ContactsLds {                  // [record][field][lane] image shared by the waves of a workgroup
     static constexpr bool COOP = true;
     T* base; int lane; unsigned char* pbase; int part = 0, nparts = 1;                 // lane: the ENV's column; part of nparts: this lane's share of it
-    int n = 0, dropped = 0, prev_n = 0;                                               // pbase: [MAXC][64] bytes OUTSIDE any aliased region
+    int n = 0, dropped = 0, prev_n = 0, sig = 0;                                      // pbase: [MAXC][64] bytes OUTSIDE any aliased region
     SO100_HD T get(int s, int f) const { return base[(s*CF + f)*64 + lane]; }
     SO100_HD void set(int s, int f, T v) { base[(s*CF + f)*64 + lane] = v; }
     SO100_HD int getp(int k) const { return pbase[k*64 + lane]; }
@@ -202,16 +206,22 @@ SO100_HD bool contact_add(Store& cs, int kind, int id, const T p[3], const T n[3
 // write record s (no budget logic: the caller owns the slot)
 template <typename T, class Store>
 SO100_HD void contact_put(Store& cs, int s, int kind, int id, const T p[3], const T n[3], T dist, const T vrel[3]) {
+    if (kind != 0) cs.sig = (int)((unsigned)cs.sig + (unsigned)contact_id_mix(id));      // signature of the pad-contact set (this lane's share)
     int mask0 = 15;                                            // a new contact: expect all four edges to push (an impact sticks first)
 #pragma unroll 1
     for (int k = 0; k < cs.prev_n; k++) { const int c = cs.getp(k); if ((c >> 4) == contact_id_hash(id)) mask0 = c & 15; }
     // impedance, reference and regulariser: R = 2 mu^2 (1 - imp)/imp * (1 + mu^2) * (translational invweight0 of both bodies), mu = 1
     T imp, K, B, tran;
     if (kind == 0) { imp = impedance(tabs(dist)); K = T(so100g::SOLREF_K); B = T(so100g::SOLREF_B); tran = T(1.0/so100g::CUBE_MASS); }
-    else {
+    else if (kind == 5) {                                      // link proxy / floor: both geoms carry MuJoCo's default parameters
+        imp = impedance(tabs(dist)); K = T(so100g::SOLREF_K); B = T(so100g::SOLREF_B);
+        const int l = contact_link(kind, id);
+        tran = l == 1 ? T(so100g::LINK_INVWEIGHT_TRAN[1]) : l == 2 ? T(so100g::LINK_INVWEIGHT_TRAN[2]) : l == 3 ? T(so100g::LINK_INVWEIGHT_TRAN[3])
+             : l == 4 ? T(so100g::LINK_INVWEIGHT_TRAN[4]) : T(so100g::LINK_INVWEIGHT_TRAN[5]);
+    } else {
         imp = impedance_pad(tabs(dist)); K = T(so100g::PADC_K); B = T(so100g::PADC_B);
         tran = (kind == 1 || kind == 3) ? T(so100g::LINK_INVWEIGHT_TRAN[4]) : T(so100g::LINK_INVWEIGHT_TRAN[5]);
-        if (kind >= 3) tran += T(1.0/so100g::CUBE_MASS);
+        if (kind == 3 || kind == 4) tran += T(1.0/so100g::CUBE_MASS);
     }
     const T R = T(4)*tran*(T(1) - imp)*trcp(imp);
     cs.set(s, C_PX, p[0]); cs.set(s, C_PY, p[1]); cs.set(s, C_PZ, p[2]);
@@ -245,6 +255,19 @@ SO100_HD void plane_box(const T c[3], const T R[9], const T h[3], Emit emit) {
             cnt++;
         }
     }
+}
+
+// the same test, returning only WHICH corners make a contact (bit k = corner k; at most 4, in corner order)
+template <typename T>
+SO100_HD unsigned plane_box_mask(const T c[3], const T R[9], const T h[3]) {
+    unsigned m = 0u; int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const T v0 = (k & 1) ? h[0] : -h[0], v1 = (k & 2) ? h[1] : -h[1], v2 = (k & 4) ? h[2] : -h[2];
+        const T lz = R[6]*v0 + R[7]*v1 + R[8]*v2;
+        if (!(c[2] + lz > T(0) || lz > T(0)) && cnt < 4) { m |= 1u << k; cnt++; }
+    }
+    return m;
 }
 
 // Box-box (see oracle/so100_oracle.c: so100o_box_box for the algorithm; this is the same sequence of operations).
@@ -438,9 +461,8 @@ template <int LINK, typename T> SO100_HD T pad_hull_lowest(const T o[3], const T
 // Returns true when at least one pad/cube contact exists.
 template <typename T, class Store>
 SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<T>& cube, const T Rc[9], unsigned flags, bool cube_live, Store& cs) {
-    cs.n = 0; cs.dropped = 0;                                 // (cs.prev_n / the previous list stay: contact_add looks the new contacts up in it)
-    Spatial<T> V4, V5;
-    link_spatial(W, v, V4, V5);
+    cs.n = 0; cs.dropped = 0; cs.sig = 0;                     // (cs.prev_n / the previous list stay: contact_add looks the new contacts up in it)
+    Spatial<T> V4{}, V5{};
     const T nz[3] = { T(0), T(0), T(1) };
     const T hc[3] = { T(so100g::CUBE_HALF), T(so100g::CUBE_HALF), T(so100g::CUBE_HALF) };
     bool coupled = false;
@@ -461,6 +483,7 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
     const bool near_floor = (flags & F_PADS_FLOOR) != 0u && zmin < T(PAD_REACH)
                             && tmin(pad_hull_lowest<4, T>(W.o[4], W.R4), pad_hull_lowest<5, T>(W.o[5], W.R5)) <= T(0);
     const bool near_cube = dc2 < T((PAD_REACH + so100g::CUBE_HALF*1.7320508075688772)*(PAD_REACH + so100g::CUBE_HALF*1.7320508075688772));
+    if (near_floor || near_cube) link_spatial(W, v, V4, V5);   // the jaws' spatial velocities (for the contacts' velocity terms): only where a pad may touch
     auto pad_frame = [&](int g, T R[9], T o[3], T h[3], T c[3]) {
         const bool l5 = so100g::PAD_LINK[g] == 5;
 #pragma unroll
@@ -480,31 +503,40 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             // them -- pad by pad, corner by corner, the first MAXPADC kept.  Same list as the serial pass, 4 (2) times faster.
             coop_floor_done = true;
             if (near_floor) {
-                int counts = 0;
+                // pass 1: which corners of MY pads touch (a 4-bit-per-pad count for the group, the corner masks stay with the lane)
+                int counts = 0; unsigned cmask = 0u;
 #pragma unroll 1
-                for (int g = cs.part; g < so100g::NPAD; g += cs.nparts) {
+                for (int g = cs.part, j = 0; g < so100g::NPAD; g += cs.nparts, j++) {
                     T R[9], o[3], h[3], c[3];
                     pad_frame(g, R, o, h, c);
-                    int cnt = 0;
-                    if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) plane_box<T>(c, R, h, [&](const T*, T, int) { cnt++; });
-                    counts |= cnt << (3*g);
+                    if (c[2] - (tabs(R[6])*h[0] + tabs(R[7])*h[1] + tabs(R[8])*h[2]) <= T(0)) {
+                        const unsigned m = plane_box_mask<T>(c, R, h);
+                        cmask |= m << (8*j); counts |= __builtin_popcount(m) << (3*g);
+                    }
                 }
                 counts = coop_or(cs, counts);
                 int total = 0;
 #pragma unroll
                 for (int g = 0; g < so100g::NPAD; g++) total += (counts >> (3*g)) & 7;
+                // pass 2: every lane writes its records at the slots the serial order gives them (pad by pad, corner by corner)
 #pragma unroll 1
-                for (int g = cs.part; g < so100g::NPAD; g += cs.nparts) {
-                    if (((counts >> (3*g)) & 7) == 0) continue;
-                    int off = 0;
-                    for (int hh = 0; hh < g; hh++) off += (counts >> (3*hh)) & 7;
+                for (int g = cs.part, j = 0; g < so100g::NPAD; g += cs.nparts, j++) {
+                    unsigned m = (cmask >> (8*j)) & 255u;
+                    if (m == 0u) continue;
+                    int slot = 0;
+                    for (int hh = 0; hh < g; hh++) slot += (counts >> (3*hh)) & 7;
                     T R[9], o[3], h[3], c[3];
                     const bool l5 = pad_frame(g, R, o, h, c);
-                    int idx = 0;
-                    plane_box<T>(c, R, h, [&](const T* p, T dist, int corner) {
-                        const int slot = off + idx++;
-                        if (slot < MAXPADC) { T vr[3]; point_motion(pick_spatial(l5, V4, V5), p, vr); contact_put(cs, slot, l5 ? 2 : 1, 8*g + corner, p, nz, dist, vr); }
-                    });
+                    const Spatial<T> V = pick_spatial(l5, V4, V5);
+#pragma unroll 1
+                    while (m != 0u && slot < MAXPADC) {
+                        const int k = __builtin_ctz(m); m &= m - 1u;
+                        const T v0 = (k & 1) ? h[0] : -h[0], v1 = (k & 2) ? h[1] : -h[1], v2 = (k & 4) ? h[2] : -h[2];
+                        const T lz = R[6]*v0 + R[7]*v1 + R[8]*v2, dist = c[2] + lz;
+                        const T p[3] = { R[0]*v0 + R[1]*v1 + R[2]*v2 + c[0], R[3]*v0 + R[4]*v1 + R[5]*v2 + c[1], lz + c[2] - T(0.5)*dist };
+                        T vr[3]; point_motion(V, p, vr);
+                        contact_put(cs, slot++, l5 ? 2 : 1, 8*g + k, p, nz, dist, vr);
+                    }
                 }
                 cs.n = total < MAXPADC ? total : MAXPADC; cs.dropped = total - cs.n;
             }
@@ -549,6 +581,40 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             }
         }
     }
+    if ((flags & F_LINKS_FLOOR) != 0u && serial_lane) {
+        // Link proxies (stand-in capsules for the arm's collision meshes, so100_model_def.h) against the floor: mjc_PlaneCapsule = a
+        // plane-sphere test at either end of the segment.  Ends: the link's joint origin and its child's (links 1-3), the far end of
+        // the jaw's pads (links 4, 5).  Velocity of the contact point from the joint screws of the links below it.
+#pragma unroll 1
+        for (int k = 0; k < so100g::NPROX; k++) {
+            const int l = k + 1;                               // PROX_LINK[k] (static_assert below)
+            const T r = T(so100g::PROX_RADIUS[k]);
+#pragma unroll 1
+            for (int e = 0; e < 2; e++) {
+                T c[3];
+                if (e == 0 || l <= 3) {
+                    const int j = e == 0 ? l : l + 1;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) c[a] = j == 1 ? W.o[1][a] : j == 2 ? W.o[2][a] : j == 3 ? W.o[3][a] : j == 4 ? W.o[4][a] : W.o[5][a];
+                } else {
+                    const T* R = l == 4 ? W.R4 : W.R5; const T* o = l == 4 ? W.o[4] : W.o[5];
+                    const T f0 = T(so100g::PROX_FAR[k][0]), f1 = T(so100g::PROX_FAR[k][1]), f2 = T(so100g::PROX_FAR[k][2]);
+                    c[0] = o[0] + R[0]*f0 + R[1]*f1 + R[2]*f2; c[1] = o[1] + R[3]*f0 + R[4]*f1 + R[5]*f2; c[2] = o[2] + R[6]*f0 + R[7]*f1 + R[8]*f2;
+                }
+                const T dist = c[2] - r;
+                if (dist > T(0)) continue;
+                const T p[3] = { c[0], c[1], c[2] - r - T(0.5)*dist };
+                T vr[3] = { T(0), T(0), T(0) };
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    T col[3]; cross(W.z[i], p, col);
+                    const T vi = i <= l ? v[i] : T(0);
+                    vr[0] += vi*(col[0] + W.oz[i][0]); vr[1] += vi*(col[1] + W.oz[i][1]); vr[2] += vi*(col[2] + W.oz[i][2]);
+                }
+                contact_add(cs, 5, 144 + 2*k + e, p, nz, dist, vr);
+            }
+        }
+    }
     if (coupled && serial_lane && (flags & F_FLOOR) != 0u) {
         plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist, int corner) {
             T vr[3]; cube_point_motion(Rc, cube.pos, cube.vel, p, vr);
@@ -556,23 +622,17 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
         });
     }
     if constexpr (Store::COOP) {
-        if (cs.nparts > 1 && (flags & F_PADS_CUBE) != 0u) {   // what the first lane appended is the group's
+        if (cs.nparts > 1 && (flags & (F_PADS_CUBE | F_LINKS_FLOOR)) != 0u) {   // what the first lane appended is the group's
             cs.n = coop_first(cs, cs.n); cs.dropped = coop_first(cs, cs.dropped); coupled = coop_first(cs, coupled ? 1 : 0) != 0;
         }
     }
     if (cs.n > 0) cs.prev_n = cs.n;                            // (the solve fills the list: every row pass leaves id | final mask per record)
+    if constexpr (Store::COOP) { if (cs.nparts > 1) cs.sig = coop_sum_int(cs, cs.sig); }     // the lanes' shares of the set's signature
     return coupled;
 }
-// signature of the set of PAD contacts in the store (cube/floor records, kind 0, are the cube block's business): see contact_id_mix
-template <class Store> SO100_HD int contact_signature(const Store& cs) {
-    unsigned sig = 0u;
-#pragma unroll 1
-    for (int s = cs.part; s < cs.n; s += cs.nparts) {
-        const int code = (int)cs.get(s, C_KIND);
-        if ((code & 7) != 0) sig += (unsigned)contact_id_mix((code >> 3) & 255);
-    }
-    return coop_sum_int(cs, (int)sig);
-}
+// signature of the set of PAD contacts in the store (cube/floor records, kind 0, are the cube block's business): the wrapping sum of
+// contact_id_mix over the records, accumulated by contact_put while the store is filled
+template <class Store> SO100_HD int contact_signature(const Store& cs) { return cs.sig; }
 
 // ---- N x N SPD systems, N = 6 or 12: LDL^T in place on the packed lower triangle -----------------------------------------
 template <int N, typename T> SO100_HD void ldln(T M[N*(N+1)/2], T Dinv[N]) {
@@ -622,7 +682,10 @@ template <typename T> SO100_HD void ldl6_reconstruct(const T L[21], T M[21]) {
 
 // ---- the primal problem of one env's substep ----------------------------------------------------------------------------
 // ND = 6: arm only (pad/floor contacts);  ND = 12: arm + cube (a pad touches the cube): x = [arm qacc (6) ; cube qacc (6)]
-template <int ND, typename T, class Store> struct PrimalProblem {
+// LINKS = false: every arm-side geom sits on link 4 or 5 (the finger pads: the default physics) -- point accelerations from the two jaws'
+// spatial accelerations, wrench totals per jaw.  LINKS = true (F_LINKS_FLOOR): a record may sit on any link 1..5; per record the six
+// Jacobian columns z_i x (p - o_i) are formed once and serve the point acceleration, the gradient and the Hessian alike.
+template <int ND, typename T, class Store, bool LINKS = false> struct PrimalProblem {
     const WorldFK<T>& W; Store& cs;
     const T* Marm;             // packed lower 6x6
     const T* tau;              // arm smooth force
@@ -648,9 +711,10 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         }
         T gc[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };           // the contacts' gradient on the cube's dofs (ND = 12)
         // contacts
-        Spatial<T> S4, S5;
-        link_spatial(W, x, S4, S5);
+        Spatial<T> S4{}, S5{};
+        if (!LINKS) link_spatial(W, x, S4, S5);
         T F45[3] = { T(0), T(0), T(0) }, T45[3] = { T(0), T(0), T(0) }, F5[3] = { T(0), T(0), T(0) }, T5[3] = { T(0), T(0), T(0) };   // wrenches on links 4 + 5, on link 5
+        T ga[6] = { T(0), T(0), T(0), T(0), T(0), T(0) };           // LINKS: the contacts' gradient on the arm's dofs, accumulated per record
 #pragma unroll 1
         for (int s = cs.part; s < cs.n; s += cs.nparts) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
@@ -660,10 +724,20 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             // n = e_z, t1 = e_y, t2 = -e_x): projections on the frame are component picks
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
             if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
-            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
-            const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube pairs, geom2 in pad/floor pairs
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind == 3 || kind == 4);
+            const T sgn = (ND == 12 && (kind == 3 || kind == 4)) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube pairs, geom2 in floor pairs
+            const int link = LINKS ? contact_link(kind, (code >> 3) & 255) : (on5 ? 5 : 4);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) };
-            if (arm_side) { T ap[3]; point_motion(pick_spatial(on5, S4, S5), p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
+            T col[6][3];                                        // LINKS: column i of the point Jacobian, zero where joint i does not move the point
+            if (LINKS) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    cross(W.z[i], p, col[i]);
+                    const bool moves = arm_side && i <= link;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { col[i][k] = moves ? col[i][k] + W.oz[i][k] : T(0); w[k] += sgn*x[i]*col[i][k]; }
+                }
+            } else if (arm_side) { T ap[3]; point_motion(pick_spatial(on5, S4, S5), p, ap); w[0] += sgn*ap[0]; w[1] += sgn*ap[1]; w[2] += sgn*ap[2]; }
             if (ND == 12 && cube_side) { T ac[3]; cube_point_motion(Rc, cpos, x + 6, p, ac); w[0] += ac[0]; w[1] += ac[1]; w[2] += ac[2]; }
             const T jn = (ND == 6 ? w[2] : dot(n, w)) + kd, j1 = ND == 6 ? w[1] : dot(t1, w), j2 = ND == 6 ? -w[0] : dot(t2, w);
             const T jar[4] = { jn + j1, jn - j1, jn + j2, jn - j2 };        // edges n +- mu t1, n +- mu t2 (mu = 1)
@@ -683,7 +757,10 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 const T cn = D*(m_[0] + m_[1] + m_[2] + m_[3]), c1 = D*(m_[0] - m_[1]), c2 = D*(m_[2] - m_[3]);
                 T Fv[3] = { -c2, c1, cn };
                 if (ND == 12) { Fv[0] = cn*n[0] + c1*t1[0] + c2*t2[0]; Fv[1] = cn*n[1] + c1*t1[1] + c2*t2[1]; Fv[2] = cn*n[2] + c1*t1[2] + c2*t2[2]; }
-                if (arm_side) {
+                if (LINKS) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) ga[i] += sgn*dot(col[i], Fv);
+                } else if (arm_side) {
                     T tq[3]; cross(p, Fv, tq);
                     const T w5 = on5 ? sgn : T(0);
 #pragma unroll
@@ -703,11 +780,16 @@ template <int ND, typename T, class Store> struct PrimalProblem {
                 T cn_[ND], c1_[ND], c2_[ND];                    // the point Jacobian's columns projected on n, t1, t2
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
+                    if (LINKS) {                                           // (columns formed above, zero where the joint does not move the point)
+                        if (ND == 6) { cn_[i] = col[i][2]; c1_[i] = col[i][1]; c2_[i] = -col[i][0]; }
+                        else { cn_[i] = sgn*dot(n, col[i]); c1_[i] = sgn*dot(t1, col[i]); c2_[i] = sgn*dot(t2, col[i]); }
+                        continue;
+                    }
                     const bool moves = arm_side && (i < 5 || on5);
-                    T col[3]; cross(W.z[i], p, col);                       // z x (p - o) = z x p + o x z
-                    col[0] += W.oz[i][0]; col[1] += W.oz[i][1]; col[2] += W.oz[i][2];
-                    if (ND == 6) { cn_[i] = moves ? col[2] : T(0); c1_[i] = moves ? col[1] : T(0); c2_[i] = moves ? -col[0] : T(0); }
-                    else { cn_[i] = moves ? sgn*dot(n, col) : T(0); c1_[i] = moves ? sgn*dot(t1, col) : T(0); c2_[i] = moves ? sgn*dot(t2, col) : T(0); }
+                    T col1[3]; cross(W.z[i], p, col1);                     // z x (p - o) = z x p + o x z
+                    col1[0] += W.oz[i][0]; col1[1] += W.oz[i][1]; col1[2] += W.oz[i][2];
+                    if (ND == 6) { cn_[i] = moves ? col1[2] : T(0); c1_[i] = moves ? col1[1] : T(0); c2_[i] = moves ? -col1[0] : T(0); }
+                    else { cn_[i] = moves ? sgn*dot(n, col1) : T(0); c1_[i] = moves ? sgn*dot(t1, col1) : T(0); c2_[i] = moves ? sgn*dot(t2, col1) : T(0); }
                 }
                 if (ND == 12) {
                     const T r[3] = { p[0] - cpos[0], p[1] - cpos[1], p[2] - cpos[2] };
@@ -736,9 +818,13 @@ template <int ND, typename T, class Store> struct PrimalProblem {
         // ---- the shares of the group's lanes meet (a group of one: nothing happens)
         if constexpr (Store::COOP) {
             if (cs.nparts > 1) {
-                if (MODE >= 1) {
+                if (MODE >= 1 && !LINKS) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) { F45[k] = coop_sum(cs, F45[k]); T45[k] = coop_sum(cs, T45[k]); F5[k] = coop_sum(cs, F5[k]); T5[k] = coop_sum(cs, T5[k]); }
+                }
+                if (MODE >= 1 && LINKS) {
+#pragma unroll
+                    for (int i = 0; i < 6; i++) ga[i] = coop_sum(cs, ga[i]);
                 }
                 if (ND == 12 && MODE >= 1) {
 #pragma unroll
@@ -759,7 +845,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #pragma unroll
                 for (int j = 0; j < 6; j++) t += sym6(Marm, i, j)*x[j];
                 const T* Fa = i == 5 ? F5 : F45; const T* Ta = i == 5 ? T5 : T45;    // z . (T - o x F) = z . T + (o x z) . F
-                g[i] = (t - tau[i]) + (dot(W.z[i], Ta) + dot(W.oz[i], Fa));
+                g[i] = (t - tau[i]) + (LINKS ? ga[i] : dot(W.z[i], Ta) + dot(W.oz[i], Fa));
             }
         }
         if (MODE == 2) {
@@ -826,21 +912,29 @@ template <int ND, typename T, class Store> struct PrimalProblem {
             const bool act = Dl > T(0) && jl < T(0);
             d1 += act ? Dl*jl*sg*dx[i] : T(0); d2 += act ? Dl*dx[i]*dx[i] : T(0);
         }
-        Spatial<T> S4, S5, D4, D5;
-        link_spatial(W, xa, S4, S5);
-        link_spatial(W, dx, D4, D5);
+        Spatial<T> S4{}, S5{}, D4{}, D5{};
+        if (!LINKS) { link_spatial(W, xa, S4, S5); link_spatial(W, dx, D4, D5); }
         T c1_ = T(0), c2_ = T(0);                                 // the contacts' share of this lane
 #pragma unroll 1
         for (int s = cs.part; s < cs.n; s += cs.nparts) {
             const T p[3] = { cs.get(s, C_PX), cs.get(s, C_PY), cs.get(s, C_PZ) };
             const T kd = cs.get(s, C_KD), D = cs.get(s, C_RINV);
-            const int kind = (int)cs.get(s, C_KIND) & 7;
+            const int code = (int)cs.get(s, C_KIND), kind = code & 7;
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
             if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
-            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind >= 3);
-            const T sgn = (ND == 12 && kind >= 3) ? T(-1) : T(1);
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind == 3 || kind == 4);
+            const T sgn = (ND == 12 && (kind == 3 || kind == 4)) ? T(-1) : T(1);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) }, wd[3] = { T(0), T(0), T(0) };
-            if (arm_side) {
+            if (LINKS) {
+                const int link = contact_link(kind, (code >> 3) & 255);
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    T c3[3]; cross(W.z[i], p, c3);
+                    const bool moves = arm_side && i <= link;
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const T ck = moves ? c3[k] + W.oz[i][k] : T(0); w[k] += sgn*xa[i]*ck; wd[k] += sgn*dx[i]*ck; }
+                }
+            } else if (arm_side) {
                 T ap[3], ad[3]; point_motion(pick_spatial(on5, S4, S5), p, ap); point_motion(pick_spatial(on5, D4, D5), p, ad);
 #pragma unroll
                 for (int k = 0; k < 3; k++) { w[k] += sgn*ap[k]; wd[k] += sgn*ad[k]; }
@@ -863,6 +957,7 @@ template <int ND, typename T, class Store> struct PrimalProblem {
 #if !defined(__HIPCC__)
 static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0, g_dbg_cnewton_signpasses = 0, g_dbg_cnewton_gradpasses = 0;     // host-only instrumentation
 static int g_dbg_cnewton_trace = 0;
+static long g_dbg_cnewton_hist[4][16] = {};               // per solve: histogram of [0] gradient + Hessian passes, [1] sign passes, [2] gradient passes, [3] line-search passes
 #endif
 #if defined(SO100_CONTACT_STATS) && defined(__HIPCC__)
 __device__ unsigned long long so100_cstats[8];          // calls, iterations, line-search passes, evals, capped calls (tools/micro/contact_bench.hip)
@@ -941,14 +1036,21 @@ SO100_HD bool lean_refine(const T* Hc, const T* L, const T* Dinv, const T g[ND],
 //   * it does not => gradient + Hessian of the set x + dx selects (eval<2> there), as before.
 // Round 2 ran a full gradient + Hessian pass + factorisation at every trial point just to learn `same`: 2 such passes per solve
 // in resting contact (1 + 1 sign pass now), 3.06 on average under the bench's random policy.
-template <int ND, typename T, class Store>
-SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND], bool warm, int* work = nullptr) {
+template <int ND, typename T, class Store, bool LINKS>
+SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters, T x[ND], bool warm, int* work = nullptr) {
     constexpr int NH = ND*(ND + 1)/2;
     constexpr bool LEAN = ND == 6;
     const bool f32 = sizeof(T) == 4;
     T last = T(0);
 #if !defined(__HIPCC__)
     g_dbg_cnewton_calls++;
+    struct HistOnExit {                                       // host-only: per-solve pass histograms (tools/host_newton_stats.py)
+        long p0 = g_dbg_cnewton_passes, l0 = g_dbg_cnewton_ls, s0 = g_dbg_cnewton_signpasses, g0 = g_dbg_cnewton_gradpasses;
+        ~HistOnExit() {
+            const long l = g_dbg_cnewton_ls - l0, f = g_dbg_cnewton_passes - p0 - l, sg = g_dbg_cnewton_signpasses - s0, gr = g_dbg_cnewton_gradpasses - g0;
+            g_dbg_cnewton_hist[0][f > 15 ? 15 : f]++; g_dbg_cnewton_hist[1][sg > 15 ? 15 : sg]++; g_dbg_cnewton_hist[2][gr > 15 ? 15 : gr]++; g_dbg_cnewton_hist[3][l > 15 ? 15 : l]++;
+        }
+    } hist_on_exit_;
 #endif
     T g[ND], H[NH], Hc[LEAN ? NH : 1];
     bool same = false;
@@ -1131,7 +1233,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store>& P, int iters, T x[ND
 // (arm_row_consts / arm_rows).  acc: warm start in (previous substep's arm acceleration), solution out.  coupled: solve the
 // cube together with the arm (cs then holds its floor contacts too); cwarm = the cube's warm start in so100_cube.hpp's
 // convention (qacc - qacc_smooth), xcube = its acceleration out.  Returns the solver residual (0 when converged).
-template <typename T, class Store>
+template <bool LINKS = false, typename T, class Store>
 SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], const WorldFK<T>& W, Store& cs, bool coupled,
                          const T cpos[3], const T cwarm[6], const T Rc[9], const T applied[3], int iters, T acc[6], T xcube[6], int* zones, int* work = nullptr) {
     const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };
@@ -1148,16 +1250,16 @@ SO100_HD T contact_solve(const T tau[6], const ArmRows<T>& r, const T Marm[21], 
     }
     const bool warm = true;
     if (!coupled) {
-        PrimalProblem<6, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
-        res = primal_newton<6>(P, iters, acc, warm, work);
+        PrimalProblem<6, T, Store, LINKS> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
+        res = primal_newton<6, T, Store, LINKS>(P, iters, acc, warm, work);
     } else {
-        PrimalProblem<12, T, Store> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
+        PrimalProblem<12, T, Store, LINKS> P{ W, cs, Marm, tau, r, Rc, cpos, a0c, zones };
         T x[12];
 #pragma unroll
         for (int i = 0; i < 6; i++) x[i] = acc[i];
 #pragma unroll
         for (int i = 0; i < 3; i++) { x[6 + i] = cwarm[i] + a0c[i]; x[9 + i] = cwarm[3 + i]; }
-        res = primal_newton<12>(P, iters, x, warm, work);
+        res = primal_newton<12, T, Store, LINKS>(P, iters, x, warm, work);
 #pragma unroll
         for (int i = 0; i < 6; i++) { acc[i] = x[i]; xcube[i] = x[6 + i]; }
     }
@@ -1180,7 +1282,8 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
     ldl6_reconstruct(A.M, Marm);
 #pragma unroll
     for (int i = 0; i < 6; i++) acc[i] = aw[i];
-    const T res = contact_solve(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones);
+    const T res = (flags & F_LINKS_FLOOR) != 0u ? contact_solve<true>(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones)
+                                                : contact_solve<false>(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones);
     if (coupled) {
         // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler
         const T a0c[3] = { applied[0]*T(1.0/so100g::CUBE_MASS), applied[1]*T(1.0/so100g::CUBE_MASS), applied[2]*T(1.0/so100g::CUBE_MASS) - T(so100g::GRAVITY) };

@@ -107,7 +107,8 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
 // throughput kernel for large batches.
 template <int KIND, int FL>
 __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
-    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
+    constexpr bool PADS = FL < 0 || (FL & (int)F_ANY_CONTACT) != 0;
+    constexpr bool LINKS = FL < 0 || (FL & (int)F_LINKS_FLOOR) != 0;
     __shared__ float xq[PADS ? 24 : 18][64];
     __shared__ float xc[24][64];
     __shared__ float xb[6][64];
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     Arm<float> A; Prof prof_;
     const PhaseLds lds{ xq, xc, xb, cbuf, xa, xk, xm, pbuf, PADS ? xw : nullptr };
     ContactMemo memo;                                             // (reset by physics_phase_mw: the memory lives for the env step's substeps)
-    physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [](int) {}, [&]() {
+    physics_phase_mw<PADS, LINKS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [](int) {}, [&]() {
         ctx = StepCtx{};
 #pragma unroll
         for (int k = 0; k < 8; k++) u[k] = 0.0f;
@@ -212,7 +213,7 @@ __global__ void __launch_bounds__(WG) so100_init_state(int n, float* state) {
 // size measured (profiles/r03_large_batch_dispatch.txt).
 constexpr int MW_MAX_ENVS = 16384;
 constexpr int MW_MAX_ENVS_PADS = 16384;    // (provisional: set from the measurement)
-inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
+inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
 struct RolloutPtrs { float* obs; float* rew; uint8_t* done; uint8_t* trunc; float* tobs; float* ep_ret; int32_t* ep_len; };

@@ -167,4 +167,19 @@ static const double SO100_PAD_SIZE[SO100_NPAD][3] = {
 /* default geom friction (sliding) used by the cube-floor contact */
 #define SO100_GEOM_FRICTION 1.0
 
+/* ---- link proxies: STAND-IN geometry, NOT numbers of the reference -----------------------------------------------------------
+ * The arm's collision geoms other than the finger pads are MESHES (class "collision", arm:58-59, used at arm:85, 92, 99, 106-107,
+ * 117-119) whose STL files are not in the reference snapshot.  Behind their own physics flag (SO100_F_LINKS_FLOOR) each of these
+ * links is given ONE capsule, built by rule from numbers that ARE in the MJCF:
+ *   links 1-3 (Upper_Arm, Lower_Arm, Wrist_Pitch_Roll): segment from the link's own joint origin to its child's joint origin
+ *     (SO100_LINK_POS of the child, arm:86, 93, 100);
+ *   links 4-5 (Fixed_Jaw, Moving_Jaw): segment from the jaw's joint origin to the far end of the box around its finger pads
+ *     (centre line of the pads in x, their largest |y|, z = 0; arm:108-111, 120-123);
+ *   radius = mean of the two SMALLER half sizes of the solid box that has the link's mass and principal inertias
+ *     (sx^2 = 6 (I_y + I_z - I_x) / m, ...; arm:73-74 ... 113-114), for the jaws capped at SO100_PROX_JAW_RADIUS_MAX.
+ * Contact parameters: MuJoCo's defaults (the meshes' class sets none).  Parity: unpinned by construction. */
+#define SO100_NPROX 5
+static const int SO100_PROX_LINK[SO100_NPROX] = { 1, 2, 3, 4, 5 };
+#define SO100_PROX_JAW_RADIUS_MAX 0.008   /* a jaw is a thin finger (pads: 8 mm half height): its inertia box -- it carries the servo -- would give a 2 cm capsule that buries the pads */
+
 #endif /* SO100_MODEL_DEF_H */

@@ -461,7 +461,7 @@ template <typename T>
 SO100_HD void arm_factor(unsigned flags, Arm<T>& A) {
     // needs only A.M: LDL^T in place (+ the explicit inverse when constraint rows are simulated)
     ldl6(A.M, A.Dinv);
-    if ((flags & (F_FRICTIONLOSS | F_LIMITS | 16u | 32u)) != 0u) ldl6_inverse(A.M, A.Dinv, A.Minv);      // 16 | 32: the pad-contact flags (so100_contact.hpp)
+    if ((flags & (F_FRICTIONLOSS | F_LIMITS | 16u | 32u | 64u)) != 0u) ldl6_inverse(A.M, A.Dinv, A.Minv);      // 16 | 32 | 64: the contact flags (so100_contact.hpp)
 }
 
 // The solve of one arm substep in separately callable stages (so100_contact.hpp puts a contact-aware Newton solve between

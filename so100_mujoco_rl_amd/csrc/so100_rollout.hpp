@@ -40,7 +40,7 @@ __device__ int so100_prof_env[16384*2];        // per env: row passes of the con
 // count (970 / 140 / 520 / 300 per pass type), [38] (workgroup, substep) pairs with a solve, [39] all pairs, [40] sum over ENVS of that estimate
 __device__ unsigned long long so100_prof_hist[48];
 struct Prof {
-    long long t[10] = {}, c = __builtin_readcyclecounter();
+    long long t[12] = {}, c = __builtin_readcyclecounter();
     int work = 0, insub = 0, sub = 0;
     // wave 3, once per substep (all its lanes): `sub` holds this substep's typed pass counts of the lane's env (0 if it did not solve)
     __device__ __forceinline__ void substep_stats(bool solved, bool first_of_env) {
@@ -64,12 +64,12 @@ struct Prof {
         sub = 0;
     }
     __device__ __forceinline__ void mark(int slot) { const long long n = __builtin_readcyclecounter(); t[slot] += n - c; c = n; }
-    __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 10; i++) so100_prof[base + i] = t[i]; }
+    __device__ __forceinline__ void flush(int base, bool who) const { if (who) for (int i = 0; i < 12; i++) so100_prof[base + i] = t[i]; }
     __device__ __forceinline__ void flush_wg(int wave, int lane, int env, bool live) const {
         if (blockIdx.x < 1024 && lane == 0) {
-            long long tot = 0; for (int i = 0; i < 10; i++) tot += t[i];
+            long long tot = 0; for (int i = 0; i < 12; i++) tot += t[i];
             if (wave == 0) { so100_prof_wg[blockIdx.x*4 + 0] = tot; so100_prof_wg[blockIdx.x*4 + 3] = t[8]; }
-            if (wave == 3) { so100_prof_wg[blockIdx.x*4 + 1] = t[4]; so100_prof_wg[blockIdx.x*4 + 2] = t[6]; }
+            if (wave == 3) { so100_prof_wg[blockIdx.x*4 + 1] = t[4] + t[10]; so100_prof_wg[blockIdx.x*4 + 2] = t[6] + t[11]; }
         }
         if (wave == 3 && live && env < 16384) { so100_prof_env[2*env] = work; so100_prof_env[2*env + 1] = insub; }
     }
@@ -130,7 +130,7 @@ struct ContactMemo { int zones = -1, prev_n = 0; };
 // tell, although those registers hold nothing on wave 3.  After its solve the contact wave therefore overwrites all of it
 // with constants (`forget`, the caller's `forget_caller_state` for what lives outside this function): every path from the
 // Newton to a use passes that definition, so the old values are dead during the solve and their registers are free.
-template <bool PADS, class Hook, class Forget>
+template <bool PADS, bool LINKS, class Hook, class Forget>
 __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, int lane, EnvState& e, float ctrl[6], float cstale[3],
                                                  Arm<float>& A, const PhaseLds& L, ContactMemo& memo, Prof& prof_, Hook after_first_barrier, Forget forget_caller_state) {
     float (*xq)[64] = L.xq; float (*xc)[64] = L.xc; float (*xb)[64] = L.xb; float (*xa)[64] = L.xa; float (*xk)[64] = L.xk; float (*xm)[64] = L.xm;
@@ -138,7 +138,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     // The cube is dynamically independent of the arm unless a pad touches it: when it is simulated (not pinned) wave 2 owns it
     // for the substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
     const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
-    const bool pads = PADS && (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
+    const bool pads = PADS && (p.flags & F_ANY_CONTACT) != 0u;
     const bool padcube = PADS && (p.flags & F_PADS_CUBE) != 0u && cube_live;
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
@@ -248,6 +248,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
 #pragma unroll
             for (int i = 0; i < 6; i++) { A3.s[i] = xq[i][el]; A3.c[i] = xq[6 + i][el]; v3[i] = xq[12 + i][el]; }
             world_fk<float>(A3.s, A3.c, W3);
+            SO100_PROF(10);                                // world FK (wave 3)
             Cube<float> c3b;
 #pragma unroll
             for (int i = 0; i < 3; i++) c3b.pos[i] = 0.0f;
@@ -330,7 +331,8 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                     for (int i = 0; i < 6; i++) cwarm[i] = xc[13 + i][el];
                     ap3[2] = xc[19][el];
                 }
-                const float res = contact_solve<float>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube, &memo.zones, SO100_PROF_WORK);
+                SO100_PROF(11);                                // contact solve set-up (wave 3)
+                const float res = contact_solve<LINKS>(tau3, r3, A3.M, W3, cs3, coupled3, cpos3, cwarm, Rc3, ap3, p.contact_iters, x3, xcube, &memo.zones, SO100_PROF_WORK);
                 SO100_PROF_INSUB();
                 if (part3 == 0) {
 #pragma unroll
@@ -566,7 +568,8 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     constexpr bool XW = FL >= 0 && (FL & (int)F_PADS_CUBE) == 0 && (FL & (int)F_PADS_FLOOR) != 0;
     static_assert(!XW || MAXPADC*CF*64 + 36*64 <= MAXC*CF*64, "joint frames must fit in the unused tail of the contact store");
     float (*xw)[64] = XW ? reinterpret_cast<float (*)[64]>(pool + MAXPADC*CF*64) : nullptr;
-    constexpr bool PADS = FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0;
+    constexpr bool PADS = FL < 0 || (FL & (int)F_ANY_CONTACT) != 0;
+    constexpr bool LINKS = FL < 0 || (FL & (int)F_LINKS_FLOOR) != 0;
     __shared__ float xa[PADS ? 15 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual, set signature
     __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase
@@ -720,7 +723,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         {
             Arm<float> A;
                         const PhaseLds lds{ xq, xc, xb, pool, xa, xk, xm, pbuf, xw };
-            physics_phase_mw<PADS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [&](int sub) {
+            physics_phase_mw<PADS, LINKS>(p, wave, lane, e, ctx.ctrl, cstale, A, lds, memo, prof_, [&](int sub) {
                 if (wave == 3 && sub == 0 && t + 1 < ra.T) {       // wave 0 has consumed xn before this barrier
                     float eps[8];
                     policy_noise(p.env_id_offset + (uint32_t)env, ra.step_counter0 + (uint32_t)(t + 1), p.seed_lo, p.seed_hi, eps);
@@ -763,7 +766,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         }
         __syncthreads();
     }
-    SO100_PROF_FLUSH(10*wave);
+    SO100_PROF_FLUSH(12*wave);
     {
         const int np = 64/p.epw, e3 = blockIdx.x*p.epw + lane/np;      // the contact wave's lanes are grouped per env
         if (wave == 3) prof_.flush_wg(wave, lane, e3, (lane % np) == 0 && e3 < p.n); else prof_.flush_wg(wave, lane, env, live);

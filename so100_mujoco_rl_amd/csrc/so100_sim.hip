@@ -80,7 +80,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     if (cfg->contact_iters < 1 || cfg->contact_iters > 64) return fail(SO100_E_INVALID, "so100_create: contact_iters must be in 1..64%s");
     if (cfg->frame_skip < 1 || cfg->frame_skip > 1024) return fail(SO100_E_INVALID, "so100_create: frame_skip must be in 1..1024%s");
     if (cfg->max_episode_steps < 0) return fail(SO100_E_INVALID, "so100_create: max_episode_steps must be >= 0%s");
-    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
+    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR))
         return fail(SO100_E_INVALID, "so100_create: unknown flag bits%s");
     if ((cfg->flags & SO100_F_PADS_CUBE) && (cfg->flags & SO100_F_CUBE_PINNED))
         return fail(SO100_E_INVALID, "so100_create: SO100_F_PADS_CUBE needs a dynamic cube (not SO100_F_CUBE_PINNED)%s");
@@ -110,7 +110,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         int epw = 64;
-        if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE))
+        if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR))
             while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
         if (cfg->envs_per_workgroup != 0) epw = (int)cfg->envs_per_workgroup;             // the caller pins it (validated above)
         s->prm.epw = epw;
@@ -127,7 +127,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     }
     {   // workgroup load balancing of the persistent rollout kernel (pad-contact variants, batches it serves; SO100_BALANCE=0 turns it off)
         const char* bal = getenv("SO100_BALANCE");
-        const bool pads = (cfg->flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE)) != 0;
+        const bool pads = (cfg->flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR)) != 0;
         if (pads && cfg->num_envs <= BALANCE_MAX_ENVS && !(bal && atoi(bal) == 0)) {
             const size_t slots = (size_t)((cfg->num_envs + s->prm.epw - 1)/s->prm.epw)*(size_t)s->prm.epw;
             if (hipMalloc(&s->slot_env, slots*sizeof(int32_t)) != hipSuccess) {

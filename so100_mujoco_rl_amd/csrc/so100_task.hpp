@@ -105,8 +105,8 @@ template <int KIND> SO100_HD constexpr bool block_kind() { return KIND == 2 || K
 // FL: the kernel's compile-time physics flags (-1 = decided at run time: every row is kept)
 template <int KIND, int FL = -1> SO100_HD constexpr bool uses_group(int g) {
     return g == 0 || (g == 1 && reach_kind<KIND>()) || (g == 2 && block_kind<KIND>()) || (g == 3 && !reach_kind<KIND>())
-        || (g == 4 && (FL < 0 || (FL & (int)(F_FRICTIONLOSS | F_LIMITS | F_PADS_FLOOR | F_PADS_CUBE)) != 0))
-        || (g == 5 && (FL < 0 || (FL & (int)(F_PADS_FLOOR | F_PADS_CUBE)) != 0));
+        || (g == 4 && (FL < 0 || (FL & (int)(F_FRICTIONLOSS | F_LIMITS | F_ANY_CONTACT)) != 0))
+        || (g == 5 && (FL < 0 || (FL & (int)F_ANY_CONTACT) != 0));
 }
 template <int KIND> SO100_HD constexpr int obs_dim() { return reach_kind<KIND>() ? 15 : 8; }
 
@@ -294,7 +294,7 @@ SO100_HD void physics_substeps(EnvState& e, const float ctrl[6], const SimParams
     Arm<float> A;
     float dq[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
     const float applied[3] = { 0.0f, 0.0f, (e.bits & B_ANTIGRAV) ? (float)(so100g::CUBE_MASS*so100g::GRAVITY) : 0.0f };
-    const bool pads = (p.flags & (F_PADS_FLOOR | F_PADS_CUBE)) != 0u;
+    const bool pads = (p.flags & F_ANY_CONTACT) != 0u;
     e.res = 0.0f; e.cstat = 0; e.csig = 0;
     ContactsPriv<float> cs; int zones = -1;                  // the contact solve's active-set memory lives for this env step
 #pragma unroll 1

@@ -15,10 +15,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SO100_LIB", os.path.join(_HERE, "libso100sim.so"))   # SO100_LIB: A/B builds of the same ABI (tools/)
 
 ENV01, ENV02, ENV03, ENV04, ENV05, ENV06 = 1, 2, 3, 4, 5, 6
-F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE = 1, 2, 4, 8, 16, 32
+F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE, F_LINKS_FLOOR = 1, 2, 4, 8, 16, 32, 64
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR | F_PADS_FLOOR     # what the reference scene simulates (minus its mesh geoms)
 F_NOPADS = F_FRICTIONLOSS | F_LIMITS | F_FLOOR                         # round-1 "reference": no arm contact at all
 F_CONTACT5 = F_REFERENCE | F_PADS_CUBE                                  # BASELINE.json configs[4]: finger pads vs cube, coupled solve
+F_REFERENCE_LINKS = F_REFERENCE | F_LINKS_FLOOR                         # + capsule proxies of the arm's collision meshes vs the floor (a documented stand-in)
 B_BAD_STATE = 128            # bit of the `bits` state row latched when a non-finite state ended an episode (csrc/so100_task.hpp)
 NINJECT = 16
 ABI_VERSION = 3              # include/so100_sim.h: SO100_ABI_VERSION

@@ -165,3 +165,53 @@ def test_workgroup_balancing_leaves_every_result_bit_identical():
         for k in ("obs", "actions", "rewards", "dones", "values", "log_probs", "last_obs"):
             assert torch.equal(a[k], b[k]), k
     assert torch.equal(qa, qb) and torch.equal(va, vb) and torch.equal(csa, csb) and torch.equal(la, lb)
+
+
+def test_link_proxies_keep_the_arm_above_the_table_on_the_gpu():
+    """SO100_F_LINKS_FLOOR (stand-in capsules for the arm's collision meshes): 512 arms that reach the table wrist / forearm first are
+    servoed further down for 40 env steps.  With the proxies every capsule end rests above -1 mm (< 3 mm dip during the impact), as in
+    the oracle; with the reference physics alone (pads only) the same links end centimetres under the table.  Run-time-flags kernels."""
+    import ctypes as C
+    from so100_mujoco_rl_amd.lib import So100Sim, F_REFERENCE_LINKS
+    from test_oracle_contacts import _wrist_first_poses, proxy_bottoms, fresh, L, M
+    n = 512
+    poses = np.array(_wrist_first_poses(64, 11))
+    rs = np.random.RandomState(2)
+    QP = np.zeros((n, 13)); QP[:, 9] = 1.0; QP[:, 6:9] = [0.2, -0.3, 0.0099]
+    QP[:, :6] = poses[rs.randint(0, len(poses), n)] + rs.uniform(-1, 1, (n, 6))*0.002
+    act = np.zeros((n, 6), np.float32); act[:, 1] = 1.0
+
+    def bottoms(qp):
+        out = []
+        for i in range(0, len(qp), 8):
+            d = fresh(qp[i, :6]); L.so100o_kinematics(C.byref(M), C.byref(d)); out.append(proxy_bottoms(d).min())
+        return np.array(out)
+
+    def run(flags):
+        sim = So100Sim(1, n, flags=flags, seed=9, max_episode_steps=0)
+        sim.reset()
+        sim.set_state(torch.from_numpy(np.ascontiguousarray(QP.T, np.float32)).cuda(), torch.zeros(12, n, device="cuda"))
+        a = torch.from_numpy(act).cuda(); low = 1.0
+        for t in range(40):
+            sim.step(a)
+            if t % 4 == 3:
+                low = min(low, bottoms(sim.get_state()[0].cpu().numpy().T).min())
+        q, v = sim.get_state()
+        return q.cpu().numpy().T, v.cpu().numpy().T, low, sim.get_field("contact_stat", dtype=torch.int32).cpu().numpy(), sim.get_field("solver_residual").cpu().numpy()
+    q, v, low, cs, res = run(F_REFERENCE_LINKS)
+    final = bottoms(q)
+    print(f"[link proxies, GPU] lowest capsule end during the run {low*1e3:.2f} mm, at the end {final.min()*1e3:.2f} mm; max |qvel| {np.abs(v[:, :6]).max():.3f}; "
+          f"envs in contact {float(((cs & 255) > 0).mean()):.2f}; worst residual {res.max():.1e}")
+    assert np.isfinite(q).all() and np.isfinite(v).all() and (cs >> 8).max() == 0
+    assert low > -0.003 and final.min() > -0.001 and ((cs & 255) > 0).mean() > 0.9
+    q0, _, _, _, _ = run(REFP)
+    assert np.median(bottoms(q0)) < -0.005                   # pads alone do not hold these poses up
+    # the oracle from the same states, same actions: same resting configuration (a sample of 16 envs)
+    worst = 0.0
+    for i in range(0, n, n//16):
+        d = fresh(); O.arr(d.qpos)[:] = QP[i].astype(np.float32)
+        for t in range(40):
+            O.arr(d.ctrl)[:] = (O.arr(d.qpos)[:6].astype(np.float32) + act[i]*np.float32(0.075)).astype(np.float64)
+            L.so100o_step(C.byref(M), C.byref(d), F_REFERENCE_LINKS, -1, 16)
+        worst = max(worst, np.abs(q[i, :6] - O.arr(d.qpos)[:6]).max())
+    assert worst < 2e-2                                       # through the impact (a make / break a substep apart), see tests/test_gpu_contacts.py

@@ -59,6 +59,17 @@ def test_pad_floor_per_substep(n, flags):
     _check(T, m*nsub//3)
 
 
+@pytest.mark.parametrize("n", [48, 8192, 16384 + 48])
+def test_link_proxies_per_substep(n):
+    """SO100_F_LINKS_FLOOR (capsule proxies of the arm's collision meshes: contacts on ANY link, the general form of the solver), through
+    the run-time-flags kernels: poses that reach the table wrist / forearm first"""
+    from test_substep_parity import wrist_first_batch, LINKS
+    m, nsub = 48, 24
+    qpos, qvel, act = wrist_first_batch(m, 0)
+    T = SH.run_substep_parity(HipDevice(n, m, LINKS), qpos, qvel, act, LINKS, nsub, f"HIP n={n} link proxies")
+    _check(T, m*nsub//3)
+
+
 @pytest.mark.parametrize("n", [64, 8192, 16384, 16384 + 64])
 def test_pad_cube_grasp_per_substep(n):
     m, nsub = 64, 40

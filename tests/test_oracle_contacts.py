@@ -322,3 +322,84 @@ def test_closing_jaw_holds_the_cube_against_gravity():
     for _ in range(40):
         _step(d, C5, 16)
     assert O.arr(d.qpos)[8] > z0 + 0.02
+
+
+# ---- link proxies (stand-in capsules for the arm's collision meshes, SO100_F_LINKS_FLOOR) -------------------------------------
+LINKS = O.F_REFERENCE | O.F_LINKS_FLOOR
+
+
+def proxy_bottoms(d):
+    """world z of the lowest point of the two end spheres of every link proxy (after so100o_kinematics)"""
+    xp = O.arr(d.xpos); xm = O.arr(d.xmat); out = []
+    for k in range(O.NPROX):
+        b = M.prox_body[k]; R = xm[b].reshape(3, 3)
+        for e in range(2):
+            out.append((xp[b] + R @ np.array(M.prox_p[k][e][:]))[2] - M.prox_radius[k])
+    return np.array(out)
+
+
+def test_link_proxy_geometry_follows_its_rule():
+    """segments run from a link's joint origin to its child's (links 1-3) or to the far end of the jaw's pads (links 4-5); radii
+    from the links' inertia boxes, jaws capped (csrc/so100_model_def.h)"""
+    d = fresh(np.array([0.3, -1.2, 1.0, 0.4, 0.2, 0.5])); L.so100o_kinematics(C.byref(M), C.byref(d))
+    xp = O.arr(d.xpos); xm = O.arr(d.xmat)
+    for k in range(3):
+        b = M.prox_body[k]; assert b == k + 3
+        assert np.allclose(np.array(M.prox_p[k][0][:]), 0)
+        assert np.allclose(xp[b] + xm[b].reshape(3, 3) @ np.array(M.prox_p[k][1][:]), xp[b + 1], atol=1e-12)      # ends at the child's joint origin
+        assert 0.015 < M.prox_radius[k] < 0.03
+    for k in (3, 4):
+        far = np.array(M.prox_p[k][1][:])
+        pads = [g for g in range(8) if M.pad_body[g] == M.prox_body[k]]
+        assert abs(far[1]) >= max(abs(M.pad_pos[g][1]) for g in pads) and M.prox_radius[k] == pytest.approx(0.008)
+
+
+def _wrist_first_poses(n, seed):
+    """arm poses whose lowest point is a LINK proxy (not a finger pad), within 3 mm above the floor"""
+    rs = np.random.RandomState(seed); out = []
+    while len(out) < n:
+        q = LO + (HI - LO)*rs.rand(6)
+        d = fresh(q); L.so100o_kinematics(C.byref(M), C.byref(d))
+        pb = proxy_bottoms(d)
+        zpad = min(c[2] - (np.abs(R[2])*h).sum() for c, R, h in pad_frames(d))
+        if 0.0 < pb[:6].min() < 0.003 and zpad > pb[:6].min() + 0.02:
+            out.append(q)
+    return out
+
+
+def test_arm_driven_wrist_first_into_the_table_stops_on_its_link_proxies():
+    """with the proxies the arm commanded downwards rests with every proxy sphere above -1 mm (a capsule end
+    dips < 3 mm during the impact); without them (reference physics: pads only) the same links sink centimetres into the table."""
+    sunk = []
+    for q0 in _wrist_first_poses(6, 3):
+        res = {}
+        for flags in (LINKS, REF):
+            d = fresh(q0)
+            low = 1.0
+            for t in range(40):
+                O.arr(d.ctrl)[:] = O.arr(d.qpos)[:6]; O.arr(d.ctrl)[1] += 0.075      # shoulder down, Env01's relative servo
+                L.so100o_step(C.byref(M), C.byref(d), flags, -1, 16)
+                L.so100o_kinematics(C.byref(M), C.byref(d)); low = min(low, proxy_bottoms(d).min())
+            res[flags] = (low, proxy_bottoms(d).min(), np.abs(O.arr(d.qvel)[:6]).max(), d.ncon)
+            assert np.all(np.isfinite(O.arr(d.qpos)))
+        low, final, vmax, ncon = res[LINKS]
+        assert low > -0.003 and final > -0.001 and vmax < 0.5
+        sunk.append(res[REF][1])
+    assert np.median(sunk) < -0.005 and min(sunk) < -0.01     # without the proxies the same links end up to centimetres under the table
+
+
+def test_link_proxy_rows_satisfy_kkt_and_newton_equals_pgs():
+    """the proxy contacts are ordinary pyramidal rows on links 1-5: the Newton solution satisfies the KKT conditions row by row"""
+    for q0 in _wrist_first_poses(4, 5):
+        q = q0.copy(); q[1] += 0.02                          # push the pose a little into the table
+        d = fresh(q, v=np.random.RandomState(1).randn(6)*0.3)
+        fwd(d, LINKS, -1)
+        assert any(d.con[i].kind == 3 for i in range(d.ncon))
+        n = d.nefc
+        J = O.arr(d.efc_J)[:n]; f = O.arr(d.efc_force)[:n]; aref = O.arr(d.efc_aref)[:n]; Rr = O.arr(d.efc_R)[:n]; ty = np.ctypeslib.as_array(d.efc_type)[:n]
+        jar = J @ O.arr(d.qacc) - aref
+        for r in range(n):
+            if ty[r] != 0:                                    # one-sided rows: f >= 0, f = max(0, -jar / R)
+                assert f[r] >= -1e-12 and abs(f[r] - max(0.0, -jar[r]/Rr[r])) < 1e-6*(1 + abs(f[r]))
+        Mq = O.arr(d.M).reshape(12, 12)
+        assert np.allclose(Mq[:6, :6] @ (O.arr(d.qacc) - O.arr(d.qacc_smooth))[:6], (J.T @ f)[:6], atol=1e-8)

@@ -83,3 +83,35 @@ def test_pad_cube_grasp_per_substep_host_fp32(H):
     qpos, qvel, act = SH.grasp_batch(n, 1)
     T = SH.run_substep_parity(HostDevice(H, n, O.F_CONTACT5), qpos, qvel, act, O.F_CONTACT5, 48, "host fp32, grasp")
     _check(T, n_pairs_min_contact=n*48//3, coupled_min=n*48//4)
+
+
+# ---- link proxies (SO100_F_LINKS_FLOOR: stand-in capsules for the arm's collision meshes, contacts on ANY link) ---------------
+LINKS = O.F_REFERENCE | O.F_LINKS_FLOOR
+
+
+def wrist_first_batch(n, seed):
+    """poses whose lowest point is a link proxy (wrist / forearm first), pushed 1e-2 rad into the table; random joint velocities"""
+    from test_oracle_contacts import _wrist_first_poses
+    rs = np.random.RandomState(seed)
+    qpos = np.zeros((n, 13)); qvel = np.zeros((n, 12))
+    for i, q in enumerate(_wrist_first_poses(n, seed + 7)):
+        qpos[i, :6] = q; qpos[i, 1] += 0.01; qpos[i, 6:9] = [0.15, -0.25, 0.0099]; qpos[i, 9] = 1.0; qvel[i, :6] = rs.randn(6)*0.3
+    act = rs.uniform(-1, 1, (n, 6)).astype(np.float32); act[:, 1] = 0.5
+    return qpos, qvel, act
+
+
+def test_link_proxies_per_substep_host_fp32(H):
+    n = 48
+    qpos, qvel, act = wrist_first_batch(n, 0)
+    T = SH.run_substep_parity(HostDevice(H, n, LINKS), qpos, qvel, act, LINKS, 32, "host fp32, link proxies, wrist first")
+    _check(T, n_pairs_min_contact=n*32//3)
+    qpos, qvel, act = SH.floor_batch(n, 0)                    # pads AND proxies on the table
+    T = SH.run_substep_parity(HostDevice(H, n, LINKS), qpos, qvel, act, LINKS, 24, "host fp32, link proxies + pads")
+    _check(T, n_pairs_min_contact=n*24//2)
+
+
+def test_link_proxies_with_the_coupled_grasp_per_substep_host_fp32(H):
+    n, flags = 24, LINKS | O.F_PADS_CUBE
+    qpos, qvel, act = SH.grasp_batch(n, 1)
+    T = SH.run_substep_parity(HostDevice(H, n, flags), qpos, qvel, act, flags, 40, "host fp32, link proxies + grasp")
+    _check(T, n_pairs_min_contact=n*40//4, coupled_min=n*40//5)

@@ -57,13 +57,14 @@ out = (C.c_longlong * 48)()
 assert sim.L.so100_prof_read(1, out) == 0
 names = ["policy layers (MFMA+tanh, 2 barriers)", "head+noise+row+env_step_pre", "trig + publish", "barrier-1 wait",
          "phase 1: CRBA+factor (w0) / RNEA (w1) / cube_prepare (w2) / FK+narrowphase (w3)", "barrier-2 wait",
-         "phase 2: PGS (w0) / cube Newton (w2) / contact Newton (w3)", "step tail: poses, obs, reset, end barrier", "barrier-3 wait", "integrate"]
+         "phase 2: PGS (w0) / cube Newton (w2) / contact Newton (w3)", "step tail: poses, obs, reset, end barrier", "barrier-3 wait", "integrate",
+         "  (w3) world FK, before the narrowphase", "  (w3) contact-solve set-up, before the Newton"]
 print(f"# tools/rollout_prof.py {which} {mode}   (Env01 x {n}, epw {16 if flags & 4 else 64})")
 for w in range(4):
-    v = [out[10 * w + i] for i in range(10)]; tot = sum(v)
+    v = [out[12 * w + i] for i in range(12)]; tot = sum(v)
     print(f"wave {w}: total {tot / T:9.0f} ticks/step")
     for nm, x in zip(names, v):
-        per = "  (%.0f / substep)" % (x / T / 16) if nm.split()[0] in ("trig", "barrier-1", "phase", "barrier-2", "barrier-3", "integrate") else ""
+        per = "  (%.0f / substep)" % (x / T / 16) if nm.split()[0] in ("trig", "barrier-1", "phase", "barrier-2", "barrier-3", "integrate", "(w3)") else ""
         print(f"    {nm:84s} {x / T:9.0f} ticks/step  {100.0 * x / max(tot, 1):5.1f} %{per}")
 
 # per-workgroup totals (the launch ends with its slowest workgroup) and per-env Newton work of the last launch
