@@ -30,6 +30,9 @@
 #if !defined(__HIPCC__)
 #include <cstdio>
 #endif
+#ifndef SO100_LS_TIGHT_AFTER
+#define SO100_LS_TIGHT_AFTER 4
+#endif
 #ifndef SO100_LEAN_DX
 #define SO100_LEAN_DX 0.02     // size of a Newton step, SO100_LEAN_ABS + SO100_LEAN_DX |x| (rad/s^2), up to which its round-off is removed by
 #endif                         // refining the LINEAR system (see primal_newton: lean_refine)
@@ -955,7 +958,7 @@ template <int ND, typename T, class Store, bool LINKS = false> struct PrimalProb
 };
 
 #if !defined(__HIPCC__)
-static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0, g_dbg_cnewton_signpasses = 0, g_dbg_cnewton_gradpasses = 0;     // host-only instrumentation
+static long g_dbg_cnewton_iters = 0, g_dbg_cnewton_ls = 0, g_dbg_cnewton_calls = 0, g_dbg_cnewton_passes = 0, g_dbg_cnewton_signpasses = 0, g_dbg_cnewton_gradpasses = 0, g_dbg_cnewton_lastiter = 0;     // host-only instrumentation
 static int g_dbg_cnewton_trace = 0;
 static long g_dbg_cnewton_hist[4][16] = {};               // per solve: histogram of [0] gradient + Hessian passes, [1] sign passes, [2] gradient passes, [3] line-search passes
 #endif
@@ -965,7 +968,7 @@ __device__ unsigned long long so100_cstats[8];          // calls, iterations, li
 #if defined(SO100_CONTACT_STATS) && defined(__HIP_DEVICE_COMPILE__)
 #define SO100_CSTAT(i) atomicAdd(&so100_cstats[i], 1ull)
 #elif !defined(__HIPCC__)
-#define SO100_CSTAT(i) ((i) == 3 || (i) == 2 ? (void)g_dbg_cnewton_passes++ : (i) == 5 ? (void)g_dbg_cnewton_signpasses++ : (i) == 6 ? (void)g_dbg_cnewton_gradpasses++ : (void)0)
+#define SO100_CSTAT(i) ((i) == 3 || (i) == 2 ? (void)g_dbg_cnewton_passes++ : (i) == 5 ? (void)g_dbg_cnewton_signpasses++ : (i) == 6 ? (void)g_dbg_cnewton_gradpasses++ : (i) == 4 ? (void)g_dbg_cnewton_lastiter++ : (void)0)
 #else
 #define SO100_CSTAT(i) ((void)0)
 #endif
@@ -1027,19 +1030,20 @@ SO100_HD bool lean_refine(const T* Hc, const T* L, const T* Dinv, const T g[ND],
     return false;
 }
 
-// LEAN (the 6-unknown problem: every default-physics solve).  The problem is piecewise quadratic, so after a FULL Newton step
+// LEAN.  The problem is piecewise quadratic, so after a FULL Newton step
 // x -> x + dx on the quadratic Q_S of an active set S the only open question is whether x + dx still selects S:
 //   * it does  => x + dx minimises the true cost.  No gradient or Hessian at the new point is needed to know that -- a pass
 //     that only evaluates the rows' signs (eval<0>: ~1/5 of a gradient + Hessian pass) answers it; the round-off of the step is
 //     removed by one iterative-refinement step of the LINEAR system on the Hessian that made the step (r = -(g + H dx) is the
-//     gradient of Q_S at x + dx; the unfactored H is kept for it: 21 registers);
+//     gradient of Q_S at x + dx; the unfactored H is kept for it: 21 registers -- 6-unknown problem only; the 12-unknown problem
+//     and large steps refine with the gradient evaluated at the new point instead, still without a Hessian or a factorisation);
 //   * it does not => gradient + Hessian of the set x + dx selects (eval<2> there), as before.
 // Round 2 ran a full gradient + Hessian pass + factorisation at every trial point just to learn `same`: 2 such passes per solve
 // in resting contact (1 + 1 sign pass now), 3.06 on average under the bench's random policy.
 template <int ND, typename T, class Store, bool LINKS>
 SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters, T x[ND], bool warm, int* work = nullptr) {
     constexpr int NH = ND*(ND + 1)/2;
-    constexpr bool LEAN = ND == 6;
+    constexpr bool LEAN = true, LINREF = ND == 6;       // LINREF: keep the unfactored Hessian for the linear refinement (21 registers; 78 would not fit)
     const bool f32 = sizeof(T) == 4;
     T last = T(0);
 #if !defined(__HIPCC__)
@@ -1052,7 +1056,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
         }
     } hist_on_exit_;
 #endif
-    T g[ND], H[NH], Hc[LEAN ? NH : 1];
+    T g[ND], H[NH], Hc[LINREF ? NH : 1];
     bool same = false;
     if (warm) {
         // Active-set warm start.  The rows are stiff (a force-carrying row sits at jar = -R f, a hair below zero), so the sign of jar at
@@ -1063,7 +1067,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
         P.template eval<2, true>(x, g, H);
         if (work) *work += 1;
         SO100_CSTAT(3);
-        if (LEAN) {
+        if (LINREF) {
 #pragma unroll
             for (int i = 0; i < NH; i++) Hc[i] = H[i];
         }
@@ -1072,7 +1076,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
         ldln<ND>(H, Dinv);
         ldln_solve<ND>(H, Dinv, dx);
         bool big = false;
-        if (LEAN) big = lean_refine<ND>(Hc, H, Dinv, g, x, dx);
+        if (LEAN) big = LINREF ? lean_refine<ND>(Hc, H, Dinv, g, x, dx) : true;
 #pragma unroll
         for (int i = 0; i < ND; i++) x[i] += dx[i];
         if (LEAN) {
@@ -1109,7 +1113,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
 #if !defined(__HIPCC__)
         g_dbg_cnewton_iters++;
 #endif
-        if (LEAN) {
+        if (LINREF) {
 #pragma unroll
             for (int i = 0; i < NH; i++) Hc[i] = H[i];
         }
@@ -1148,7 +1152,7 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
                 T d2[ND];
 #pragma unroll
                 for (int i = 0; i < ND; i++) d2[i] = dx[i];
-                const bool big = lean_refine<ND>(Hc, H, Dinv, g, x, d2);
+                const bool big = LINREF ? lean_refine<ND>(Hc, H, Dinv, g, x, d2) : true;
 #pragma unroll
                 for (int i = 0; i < ND; i++) x[i] += d2[i];
                 if (big) {
@@ -1188,7 +1192,10 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
             continue;
         }
         small_prev = false;
-        if (progress || d1 <= T(0.5)*tabs(gdx)) {
+#ifndef SO100_ACCEPT_RULE
+#define SO100_ACCEPT_RULE (progress || d1 <= T(0.5)*tabs(gdx))
+#endif
+        if (SO100_ACCEPT_RULE) {
 #pragma unroll
             for (int i = 0; i < ND; i++) { x[i] = xn[i]; g[i] = gn[i]; }
             E0 = E1;
@@ -1197,15 +1204,21 @@ SO100_HD T primal_newton(const PrimalProblem<ND, T, Store, LINKS>& P, int iters,
         // the full step overshot: exact line search in (0, 1) by safeguarded Newton on phi', first trial from the secant of
         // phi'(0) = g.dx < 0 and phi'(1) = d1 > 0
         T lo = T(0), hi = T(1), alpha = gdx/(gdx - d1), d2;
+        // A crude minimiser (2 trials, |phi'| <= 1/4 |phi'(0)|) is the cheapest way through an impact, but near the solution it can trap the
+        // iteration in a 2-cycle over a kink of a friction-loss row (measured: 1.5e-4 of the solves under the bench's random policy ran into
+        // their iteration cap that way): from the SO100_LS_TIGHT_AFTER-th iteration on the search is run to |phi'| <= 1/50 |phi'(0)| with up
+        // to 8 trials -- an exact line search cannot cycle (the cost decreases strictly)
+        const bool tight = f32 && it >= SO100_LS_TIGHT_AFTER;
+        const T ls_tol = f32 ? (tight ? T(0.02) : T(0.25)) : T(1e-10);
 #pragma unroll 1
-        for (int ls = 0; ls < (f32 ? (ND == 12 ? 6 : SO100_LS_PASSES) : 40); ls++) {      // (the coupled problem with its 8 g cube needs the better minimiser)
+        for (int ls = 0; ls < (f32 ? (tight ? 8 : (ND == 12 ? 6 : SO100_LS_PASSES)) : 40); ls++) {      // (the coupled problem with its 8 g cube needs the better minimiser)
             P.line_deriv(x, dx, alpha, d1, d2);
             if (work) *work += 1 << 24;
             SO100_CSTAT(2);
 #if !defined(__HIPCC__)
             g_dbg_cnewton_ls++;
 #endif
-            if (tabs(d1) <= (f32 ? T(0.25) : T(1e-10))*tabs(gdx)) break;
+            if (tabs(d1) <= ls_tol*tabs(gdx)) break;
             if (d1 < T(0)) lo = alpha; else hi = alpha;
             T an = d2 > T(0) ? alpha - d1*trcp(d2) : alpha;
             if (!(an > lo && an < hi)) an = T(0.5)*(lo + hi);

@@ -98,6 +98,7 @@ void hc_cdbg_counters(long* out) { out[0] = g_dbg_cnewton_calls; out[1] = g_dbg_
 long hc_cdbg_passes(void) { return g_dbg_cnewton_passes; }
 long hc_cdbg_signpasses(void) { return g_dbg_cnewton_signpasses; }
 long hc_cdbg_gradpasses(void) { return g_dbg_cnewton_gradpasses; }
+long hc_cdbg_lastiter(void) { return g_dbg_cnewton_lastiter; }
 void hc_cdbg_hist(long* out64, int reset) { for (int i = 0; i < 64; i++) { out64[i] = (&g_dbg_cnewton_hist[0][0])[i]; if (reset) (&g_dbg_cnewton_hist[0][0])[i] = 0; } }
 int hc_contact_id_hash(int id) { return contact_id_hash(id); }
 }

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "_hostcheck"), "-s"])
 H = C.CDLL(os.path.join(ROOT, "tests", "_hostcheck", os.environ.get("HC_LIB", "libhostcheck.so")))
 H.hc_env_new.restype = C.c_void_p
-for f in ("hc_cdbg_passes", "hc_cdbg_signpasses", "hc_cdbg_gradpasses"):
+for f in ("hc_cdbg_passes", "hc_cdbg_signpasses", "hc_cdbg_gradpasses", "hc_cdbg_lastiter"):
     getattr(H, f).restype = C.c_long
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
@@ -34,4 +34,4 @@ print(f"{n} envs x {steps} steps; env-steps with a pad contact {touching/(n*step
 for name, row in zip(("grad+Hessian", "sign", "gradient", "line-search"), h):
     print(f"  {name:13s} passes per solve: mean {(row*np.arange(16)).sum()/max(solves,1):.2f}   " + " ".join(f"{k}:{100.0*v/max(solves,1):.1f}%" for k, v in enumerate(row) if v))
 cost = 970*(h[0]*np.arange(16)).sum() + 140*(h[1]*np.arange(16)).sum() + 520*(h[2]*np.arange(16)).sum() + 300*(h[3]*np.arange(16)).sum()
-print(f"  estimated instructions per solve: {cost/max(solves,1):.0f}")
+print(f"  estimated instructions per solve: {cost/max(solves,1):.0f};  solves with >= 12 / >= 15 gradient + Hessian passes: {h[0][12:].sum()} / {h[0][15]};  solves that reached their last allowed iteration (whole run): {H.hc_cdbg_lastiter()}")
