@@ -545,11 +545,61 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             }
         }
     }
-    const bool serial_lane = !Store::COOP || cs.part == 0;   // the pad/cube pass and the cube's own floor contacts run on the group's first lane
+    bool coop_cube_done = false;
+    if constexpr (Store::COOP) {
+        if (cs.nparts > 1 && (flags & F_PADS_CUBE) != 0u && cube_live) {
+            // Pad/cube pass dealt out over the env's lanes in ROUNDS of nparts pads (round r: pad r nparts + part, so the lanes of a round hold
+            // consecutive pads): every lane runs the box-box routine for its pad into registers, the round's counts meet, and the records go
+            // to the slots the serial pad order gives them.  A closing grasp touches 2-4 pads: their 1400-instruction separating-axis +
+            // clipping runs side by side instead of one after the other (the coupled env is what a CONTACT5 launch waits for).
+            coop_cube_done = true;
+            if (near_cube) {                                   // (cs.n / cs.dropped are the same in all lanes of the group after the floor pass)
+                int base = cs.n, dropped = cs.dropped;
+#pragma unroll 1
+                for (int r = 0; r < so100g::NPAD/cs.nparts; r++) {
+                    const int g = r*cs.nparts + cs.part;
+                    T R[9], o[3], h[3], c[3];
+                    const bool l5 = pad_frame(g, R, o, h, c);
+                    T bp[8][3], bd[8], nrm[3] = { T(0), T(0), T(1) };
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { bp[q][0] = bp[q][1] = bp[q][2] = T(0); bd[q] = T(0); }
+                    int k = 0;
+                    const T dx = c[0] - cube.pos[0], dy = c[1] - cube.pos[1], dz = c[2] - cube.pos[2];
+                    const T rr = tsqrt(h[0]*h[0] + h[1]*h[1] + h[2]*h[2]) + T(so100g::CUBE_HALF*1.7320508075688772);
+                    if (dx*dx + dy*dy + dz*dz < rr*rr) {
+                        int cnt = 0;
+                        k = box_box<T>(c, R, h, cube.pos, Rc, hc, nrm, [&](const T* p, T dist) {
+#pragma unroll
+                            for (int q = 0; q < 8; q++) if (q == cnt) { bp[q][0] = p[0]; bp[q][1] = p[1]; bp[q][2] = p[2]; bd[q] = dist; }     // (no dynamic register indexing)
+                            cnt++;
+                        });
+                    }
+                    const int counts = coop_or(cs, k << (4*cs.part));
+                    int before = 0, total = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { const int cj = (counts >> (4*j)) & 15; total += cj; before += j < cs.part ? cj : 0; }
+                    const Spatial<T> V = pick_spatial(l5, V4, V5);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        if (i < k && base + before + i < MAXPADC) {
+                            T va[3], vc[3]; point_motion(V, bp[i], va); cube_point_motion(Rc, cube.pos, cube.vel, bp[i], vc);
+                            const T vr[3] = { vc[0] - va[0], vc[1] - va[1], vc[2] - va[2] };
+                            contact_put(cs, base + before + i, l5 ? 4 : 3, 64 + 8*g + i, bp[i], nrm, bd[i], vr);
+                        }
+                    }
+                    coupled = coupled || total > 0;
+                    const int nn = base + total < MAXPADC ? base + total : MAXPADC;
+                    dropped += base + total - nn; base = nn;
+                }
+                cs.n = base; cs.dropped = dropped;
+            }
+        }
+    }
+    const bool serial_lane = !Store::COOP || cs.part == 0;   // the serial passes and the cube's own floor contacts run on the group's first lane
 #pragma unroll 1
     for (int pass = 0; pass < 2; pass++) {                   // pass 0: pad/floor, pass 1: pad/cube
         if (pass == 0 && coop_floor_done) continue;
-        if (pass == 1 && !serial_lane) continue;
+        if (pass == 1 && (coop_cube_done || !serial_lane)) continue;
         if (pass == 0 && !near_floor) continue;
         if (pass == 1 && !near_cube) continue;
         if (pass == 0 && (flags & F_PADS_FLOOR) == 0u) continue;

@@ -278,7 +278,11 @@ template <int KIND> hipError_t KindOps<KIND>::rollout(const SimParams& prm, floa
     const dim3 grid((unsigned)((prm.n + prm.epw - 1)/prm.epw));
 #define SO100_RL(FLV) hipLaunchKernelGGL((so100_rollout_fused<KIND, FLV, 4>), grid, dim3(256), 0, st, prm, state, start_tab, \
         io.obs, io.rew, io.done, io.trunc, io.tobs, io.ep_ret, io.ep_len, pw, ra)
-    if (prm.flags == SO100_F_CUBE_PINNED) SO100_RL(SO100_F_CUBE_PINNED);
+    if (prm.flags == SO100_F_CUBE_PINNED) {
+        if (prm.epw <= 32) hipLaunchKernelGGL((so100_rollout_fused<KIND, SO100_F_CUBE_PINNED, 4, 32>), grid, dim3(256), 0, st, prm, state, start_tab,
+                                              io.obs, io.rew, io.done, io.trunc, io.tobs, io.ep_ret, io.ep_len, pw, ra);
+        else SO100_RL(SO100_F_CUBE_PINNED);
+    }
     else if (prm.flags == SO100_F_NOPADS) SO100_RL(SO100_F_NOPADS);
     else if (prm.flags == SO100_F_REFERENCE) SO100_RL(SO100_F_REFERENCE);
     else if (prm.flags == SO100_F_CONTACT5 && reach_kind<KIND>()) { if constexpr (reach_kind<KIND>()) SO100_RL(SO100_F_CONTACT5); }

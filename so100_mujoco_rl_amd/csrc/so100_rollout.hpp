@@ -543,12 +543,17 @@ __global__ void __launch_bounds__(256, 2) so100_policy_forward_mfma(int n, Polic
 // with the VALU policy kernel).  4 waves = one per SIMD: wave w owns tower w>>1, env rows [32(w&1), +32) and both 32-unit
 // column tiles; its B fragments (weights) stay in VGPRs for the whole launch, A fragments (activations) come from LDS in
 // [env][unit] layout with a 65-float row stride (conflict-free for the A read, the D write and the per-lane head read).
-template <int KIND, int FL, int NW>
+// ROWS = 32: the workgroup serves at most 32 envs (p.epw <= 32: a batch of <= 8192 envs spread over all 256 CUs).  The policy phase then has ONE
+// 32-row tile per tower, so wave w owns (tower w >> 1, COLUMN tile w & 1) instead of (tower, row tile) x both column tiles: 40 MFMAs per wave and
+// step instead of 80, half the tanh / LDS traffic, 40 weight registers fewer.  Same k-ordered fmaf chains: results are bit-identical.
+template <int KIND, int FL, int NW, int ROWS = 64>
 __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float* __restrict__ state, const float* start_tab,
                                                              float* obs_out, float* rew_out, uint8_t* done_out, uint8_t* trunc_out,
                                                              float* tobs_out, float* ep_ret_out, int32_t* ep_len_out,
                                                              PolicyWeights w, RolloutArgs ra) {
     static_assert(NW == 4, "one wave per SIMD: (tower, row tile) per wave");
+    static_assert(ROWS == 64 || ROWS == 32, "envs per workgroup the policy phase is tiled for");
+    constexpr bool HALF = ROWS == 32;
     constexpr int OD = obs_dim<KIND>();
     constexpr int ODP = (OD + 3) & ~3;                            // K of layer 1, padded with zero weights
     constexpr int LD = 65;                                        // LDS row stride of the [env][unit] activation images
@@ -595,11 +600,13 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     // registers to spare; the constrained variants do not (they spilled to scratch), so there the fragments live in 64 KB of
     // LDS [wave][column tile][k step][lane] and are read back right before each MFMA (measured: +3..4 % / -0.5 %).
     constexpr bool W2_LDS = FL != (int)F_CUBE_PINNED;
-    float bw1[2][ODP/2], bw2[2][W2_LDS ? 1 : 32], b1v[2], b2v[2];
+    static_assert(!HALF || !W2_LDS, "the 32-row tiling exists for the contact-disabled variant");
+    constexpr int NCT = HALF ? 1 : 2;                             // column tiles per wave
+    float bw1[NCT][ODP/2], bw2[NCT][W2_LDS ? 1 : 32], b1v[NCT], b2v[NCT];
     __shared__ float w2s[W2_LDS ? 4 : 1][2][32][W2_LDS ? 64 : 1];
 #pragma unroll
-    for (int ct = 0; ct < 2; ct++) {
-        const int unit = 32*ct + lj;
+    for (int ct = 0; ct < NCT; ct++) {
+        const int unit = 32*(HALF ? rt : ct) + lj;
         b1v[ct] = Bi1[unit]; b2v[ct] = Bi2[unit];
 #pragma unroll
         for (int s2 = 0; s2 < ODP/2; s2++) { const int k = 2*s2 + lh; bw1[ct][s2] = k < OD ? W1[unit*OD + k] : 0.0f; }
@@ -632,7 +639,15 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     for (int t = 0; t < ra.T; t++) {
         SO100_PROF(7);
         // ---- layer 1: K = ODP
-        {
+        if constexpr (HALF) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = b1v[0];
+#pragma unroll
+            for (int s2 = 0; s2 < ODP/2; s2++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(oxt[lj][2*s2 + lh], bw1[0][s2], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) h1t[tower][(r & 3) + 8*(r >> 2) + 4*lh][32*rt + lj] = fast_tanh(acc[r]);
+        } else {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc0[r] = b1v[0]; acc1[r] = b1v[1]; }
@@ -650,7 +665,15 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         }
         __syncthreads();
         // ---- layer 2: K = 64
-        {
+        if constexpr (HALF) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = b2v[0];
+#pragma unroll
+            for (int s2 = 0; s2 < 32; s2++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(h1t[tower][lj][2*s2 + lh], bw2[0][s2], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; r++) h2t[tower][(r & 3) + 8*(r >> 2) + 4*lh][32*rt + lj] = fast_tanh(acc[r]);
+        } else {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; r++) { acc0[r] = b2v[0]; acc1[r] = b2v[1]; }

@@ -112,6 +112,9 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         int epw = 64;
         if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR))
             while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
+        // contact disabled (no data-dependent solve): 32 envs per workgroup while that fits the CUs -- the persistent kernel's policy phase then
+        // runs one 32-row MFMA tile per tower instead of two (so100_rollout_fused<K, 8, 4, 32>: half the matrix-core time per step)
+        if (cfg->flags == SO100_F_CUBE_PINNED && (cfg->num_envs + 31)/32 <= cus) epw = 32;
         if (cfg->envs_per_workgroup != 0) epw = (int)cfg->envs_per_workgroup;             // the caller pins it (validated above)
         s->prm.epw = epw;
         s->prm.mw_max = mw_max_envs_for(cfg->flags);

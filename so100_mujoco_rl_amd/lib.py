@@ -327,6 +327,13 @@ class So100Sim:
         self._host_out = None
         self._obs.copy_(torch.from_numpy(obs))
 
+    def contacts_dropped(self):
+        """int32 [N]: contacts dropped over the 16-record budget in the last env step (0 where the contact flags are off).  MuJoCo would keep
+        them: an env that reports > 0 deviates from the reference model in that step (a jaw lying flat on the table)."""
+        if (self.cfg.flags & (F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR)) == 0:
+            return torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        return self.get_field("contact_stat", dtype=torch.int32) >> 8
+
     def bad_state_mask(self):
         """bool [N]: envs whose episode was ever ended by the non-finite state guard (NaN / inf action or state)."""
         return (self.get_field("bits", dtype=torch.int32) & B_BAD_STATE) != 0

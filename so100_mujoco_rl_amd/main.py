@@ -131,6 +131,9 @@ def train(ctx, environment, envs, iters, seed):
                 mean_ep = ep_sum / ep_cnt if ep_cnt else float("nan")
                 logger.info(f"iter {it:5d}  timesteps {steps/1e6:8.1f} M  reward/step {stats['mean_reward']:+.4f}  ep_rew_mean {mean_ep:9.2f}  "
                             f"value_loss {stats['value_loss']:.4f}  fps {steps/(time.time()-t0)/1e6:.1f} M")
+                dropped = int(env.sim.contacts_dropped().max().item())
+                if dropped > 0:                              # over the contact budget: this step deviates from the reference model (MuJoCo keeps every contact)
+                    logger.warning(f"contact budget exceeded: up to {dropped} contacts dropped in an env of the last step")
                 score = stats["mean_reward"]
                 if score > best:
                     best, since_best = score, 0
