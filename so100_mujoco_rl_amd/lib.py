@@ -175,13 +175,11 @@ class So100Sim:
         h = self._host_out
         if h is not None:
             self._host_out = None
-            for dst, src in zip((self._obs, self._rew, self._done, self._trunc), h[:4]):
-                dst.copy_(src, non_blocking=True)
-            done = self._done != 0                      # terminal_obs / episode statistics are only written where an episode ended
-            for dst, src in zip((self._terminal_obs, self._ep_return, self._ep_length), h[4:]):
+            # obs / rew / done / trunc are rewritten for every env by every step; terminal_obs / ep_return / ep_length only where an episode ended --
+            # the caller's host buffers persist from step to step, so they hold the latest value of every env: whole-buffer copies are right for all seven
+            for dst, src in zip((self._obs, self._rew, self._done, self._trunc, self._terminal_obs, self._ep_return, self._ep_length), h):
                 if src is not None:
-                    m = done if dst.dim() == 1 else done[:, None]
-                    dst.copy_(torch.where(m, src.to(self.device, non_blocking=True), dst))
+                    dst.copy_(src, non_blocking=True)
 
     obs = property(lambda self: (self._refresh(), self._obs)[1])
     rew = property(lambda self: (self._refresh(), self._rew)[1])
@@ -228,8 +226,7 @@ class So100Sim:
         over the host link itself -- one launch, no copy nodes (So100VecEnv's numpy path: 62 instead of 94 us per step at 4096 envs).
         The results are valid after the stream is synchronised; the handle's device-side obs / rew / done ... tensors are refreshed
         from these buffers lazily, on their next read (`_refresh`) -- so the buffers must stay alive and unmodified until then
-        (So100VecEnv owns them and only the next step_host() overwrites them, stream-ordered after the refresh)."""
-        self._refresh()                                 # an older pending mirror must land before this step overwrites its source
+        (So100VecEnv owns them; a following step_host() simply supersedes a mirror that nobody asked for: the numpy loop pays nothing)."""
         io = StepIO(_hptr(act, torch.float32, (self.n, 6)), _hptr(obs, torch.float32, (self.n, self.obs_dim)), _hptr(rew, torch.float32, (self.n,)),
                     _hptr(done, torch.uint8, (self.n,)), _hptr(trunc, torch.uint8, (self.n,)),
                     _hptr(terminal_obs, torch.float32, (self.n, self.obs_dim)), _hptr(ep_return, torch.float32, (self.n,)),

@@ -22,6 +22,7 @@ import torch
 from . import constants as K
 import torch.distributed as dist
 
+from .callbacks import EvalCallback, StopTrainingOnNoModelImprovement, StopTrainingOnRewardThreshold
 from .collector import RolloutCollector
 from .lib import F_REFERENCE
 from .ppo import PPO, ActorCritic
@@ -114,10 +115,19 @@ def train(ctx, environment, envs, iters, seed):
     if distributed:
         broadcast_policy(list(learner.net.state_dict().values()), src=0)          # every rank starts from rank 0's weights
     col = RolloutCollector(env, learner.net.state_dict(), T=64)
-    threshold = K.REWARD_THRESHOLD[kind]                     # StopTrainingOnRewardThreshold (ref: main.py:211)
-    best, since_best, steps, t0, it = -float("inf"), 0, 0, time.time(), 0
+    threshold = K.REWARD_THRESHOLD[kind]                     # StopTrainingOnRewardThreshold (ref: main.py:211; the registered threshold of the env id)
+    steps, t0, it = 0, time.time(), 0
     ep_sum = ep_cnt = 0.0
     stop = torch.zeros(1, device=env.device)
+    eval_cb = None
+    if lead:
+        # ref: main.py:211-225 -- EvalCallback(best_model_save_path, callback_on_new_best = StopTrainingOnRewardThreshold, callback_after_eval =
+        # StopTrainingOnNoModelImprovement(max_no_improvement_evals=5, min_evals=10000)), restated for the built-in learner (callbacks.py).  The reference
+        # evaluates every 20 000 timesteps of ONE env; here an update is 64 x envs timesteps, so an evaluation every EVAL_EVERY updates.
+        eval_env = So100VecEnv(environment, N_EVAL_EPISODES, device=env.device, flags=F_REFERENCE, seed=seed + 1000)
+        eval_col = RolloutCollector(eval_env, learner.net.state_dict(), T=64, bootstrap_truncated=False)
+        eval_cb = EvalCallback(lambda: _evaluate(eval_env, eval_col, learner), lambda: torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt")),
+                               EVAL_EVERY, on_new_best=StopTrainingOnRewardThreshold(threshold), after_eval=StopTrainingOnNoModelImprovement(5, 10000), log=logger.info)
     while True:
         b = col.collect(gather_dst=0 if distributed else None)
         it += 1
@@ -134,29 +144,49 @@ def train(ctx, environment, envs, iters, seed):
                 dropped = int(env.sim.contacts_dropped().max().item())
                 if dropped > 0:                              # over the contact budget: this step deviates from the reference model (MuJoCo keeps every contact)
                     logger.warning(f"contact budget exceeded: up to {dropped} contacts dropped in an env of the last step")
-                score = stats["mean_reward"]
-                if score > best:
-                    best, since_best = score, 0
-                    torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt"))
-                else:
-                    since_best += 1
-                if ep_cnt and mean_ep >= threshold:
-                    logger.info(f"Stopping training: mean episode reward {mean_ep:.1f} reached the threshold {threshold}"); stop.fill_(1.0)
                 ep_sum = ep_cnt = 0.0
+            if not eval_cb.step():
+                logger.info(f"Stopping training: best evaluation reward {eval_cb.best_mean_reward:.1f} (threshold {threshold})"); stop.fill_(1.0)
             if it % 40 == 0:                                 # CheckpointCallback (ref: main.py:227-232)
                 torch.save(learner.net.state_dict(), os.path.join(save_dir, f"{environment}_{algorithm}_cp__{steps}_steps.pt"))
-            if (iters and it >= iters) or since_best >= 50:
+            if iters and it >= iters:
                 stop.fill_(1.0)
         if distributed:
             broadcast_policy(list(learner.net.state_dict().values()) + [stop], src=0)
         col.load_policy(learner.net.state_dict())
         if stop.item() > 0:
             break
+    if lead and eval_cb.n_evals == 0:                        # a short run (--iters): one evaluation at the end, so that best_model exists
+        eval_cb.eval_every = 1; eval_cb.step()
     if lead:
         torch.save(learner.net.state_dict(), os.path.join(save_dir, "last_model.pt"))
-        logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best reward/step {best:+.4f}; models in {save_dir}")
+        logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best evaluation reward {eval_cb.best_mean_reward:.1f} ({eval_cb.n_evals} evaluations); models in {save_dir}")
     if distributed:
         dist.barrier(); dist.destroy_process_group()
+
+
+N_EVAL_EPISODES = 5       # SB3 EvalCallback's default n_eval_episodes (ref: main.py:217-224 passes none)
+EVAL_EVERY = 50           # updates between evaluations (an update is 64 x envs timesteps; the reference's eval_freq is 20 000 timesteps of one env)
+
+
+@torch.no_grad()
+def _evaluate(eval_env, eval_col, learner):
+    """SB3 evaluate_policy(deterministic=True) over N_EVAL_EPISODES episodes: one env per episode, the policy's MEAN action (log_std -> -30
+    in the copy the kernels read), every env's FIRST episode after a reset; returns the mean episode reward."""
+    sd = {k: v.clone() for k, v in learner.net.state_dict().items()}
+    sd["log_std"] = torch.full_like(sd["log_std"], -30.0)
+    eval_col.load_policy(sd)
+    eval_env.reset_tensor(); eval_col._started = True
+    n = eval_env.num_envs
+    ret = torch.zeros(n, device=eval_env.device); alive = torch.ones(n, dtype=torch.bool, device=eval_env.device)
+    for _ in range(eval_env.sim.cfg.max_episode_steps // eval_col.T + 2):
+        b = eval_col.collect()
+        for t in range(b["rewards"].shape[0]):
+            ret += torch.where(alive, b["rewards"][t], torch.zeros_like(ret))
+            alive &= ~(b["dones"][t] > 0)
+        if not bool(alive.any()):
+            break
+    return float(ret.mean().item())
 
 
 def _rollout_policy(environment, algorithm, model_file, n, steps, show_io, show_i, record_path=None):

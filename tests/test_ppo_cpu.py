@@ -83,3 +83,21 @@ def test_reported_mean_reward_is_the_env_reward_not_the_bootstrapped_one():
     assert stats["mean_bootstrapped_reward"] > stats["mean_reward"] + 5.0          # 5 of 32 steps got +49.5
     del b["raw_reward_mean"]                                                         # a caller without the statistic: falls back to the buffer's mean
     assert abs(ppo.update(b)["mean_reward"] - stats["mean_bootstrapped_reward"]) < 1e-5
+
+
+def test_eval_and_stop_callbacks_follow_sb3_semantics():
+    """EvalCallback + StopTrainingOnRewardThreshold + StopTrainingOnNoModelImprovement as the reference wires them (main.py:211-225)"""
+    from so100_mujoco_rl_amd.callbacks import EvalCallback, StopTrainingOnRewardThreshold, StopTrainingOnNoModelImprovement
+    scores = iter([1.0, 3.0, 2.0, 2.5, 2.9, 2.0, 1.0, 0.5, 0.1, 10.0])
+    saved = []
+    cb = EvalCallback(lambda: next(scores), lambda: saved.append(cb.best_mean_reward), eval_every=2,
+                      on_new_best=StopTrainingOnRewardThreshold(6.0), after_eval=StopTrainingOnNoModelImprovement(max_no_improvement_evals=3, min_evals=2))
+    out = [cb.step() for _ in range(14)]
+    # evaluations happen on calls 2, 4, 6, ...: bests 1.0 and 3.0 are saved; from the 2nd evaluation on, non-improving evaluations are counted:
+    # 2.0, 2.5, 2.9 (3 in a row: still allowed), 2.0 is the 4th -> stop on call 12
+    assert saved == [1.0, 3.0] and cb.n_evals == 7 and cb.best_mean_reward == 3.0
+    assert out[:11] == [True]*11 and out[11] is False
+    cb2 = EvalCallback(lambda: 7.0, lambda: None, eval_every=1, on_new_best=StopTrainingOnRewardThreshold(6.0))
+    assert cb2.step() is False                               # a new best at / above the threshold stops the training
+    cb3 = EvalCallback(lambda: 1.0, lambda: None, eval_every=1, after_eval=StopTrainingOnNoModelImprovement(5, 10000))
+    assert all(cb3.step() for _ in range(50))                # the reference's min_evals = 10000: this rule practically never fires
