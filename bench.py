@@ -105,10 +105,10 @@ def cpu_baseline(kind, flags, iters, seconds=10.0):
         b = O.OracleBatch(kind, n, flags, iters, seed=1234)
         b.reset()
         acts = np.random.RandomState(0).uniform(-1, 1, (n, 6)).astype(np.float32)
-        b.step(acts, threads=threads)                      # warm-up
+        b.step(acts, threads=threads, native_threads=True)  # warm-up (pthreads inside the oracle library: one slice of 64 envs per thread)
         t0 = time.perf_counter(); steps = 0
         while time.perf_counter() - t0 < secs:
-            b.step(acts, threads=threads); steps += 1
+            b.step(acts, threads=threads, native_threads=True); steps += 1
         dt = time.perf_counter() - t0
         return n * steps / dt, n, steps, dt
     v, n, steps, dt = measure(cores, seconds)

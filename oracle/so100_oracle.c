@@ -1356,6 +1356,33 @@ void so100o_envs_step_range(const so100o_model* m, so100o_env* envs, int begin, 
     }
 }
 
+/* the same over `nthreads` host threads, one contiguous env slice each (envs are independent): bench.py's cpu_baseline on all the host's
+ * cores -- a Python thread pool spends more time dispatching 256 slices than the slices take */
+#include <pthread.h>
+typedef struct { const so100o_model* m; so100o_env* envs; int begin, end; const float* actions; int autoreset; float* obs; float* rew;
+                 uint8_t* term; uint8_t* trunc; float* tobs; } so100o_slice;
+static void* slice_main(void* a) {
+    so100o_slice* s = (so100o_slice*)a;
+    so100o_envs_step_range(s->m, s->envs, s->begin, s->end, s->actions, s->autoreset, s->obs, s->rew, s->term, s->trunc, s->tobs);
+    return NULL;
+}
+int so100o_envs_step_threads(const so100o_model* m, so100o_env* envs, int n, int nthreads, const float* actions, int autoreset, float* obs,
+                             float* rew, uint8_t* term, uint8_t* trunc, float* terminal_obs) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > n) nthreads = n;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t)*(size_t)nthreads);
+    so100o_slice* sl = (so100o_slice*)malloc(sizeof(so100o_slice)*(size_t)nthreads);
+    if (!th || !sl) { free(th); free(sl); return -1; }
+    int started = 0;
+    for (int k = 0; k < nthreads; k++) {
+        sl[k] = (so100o_slice){ m, envs, (int)((long long)n*k/nthreads), (int)((long long)n*(k + 1)/nthreads), actions, autoreset, obs, rew, term, trunc, terminal_obs };
+        if (pthread_create(&th[k], NULL, slice_main, &sl[k]) != 0) { slice_main(&sl[k]); th[k] = (pthread_t)0; } else started++;
+    }
+    for (int k = 0; k < nthreads; k++) if (th[k] != (pthread_t)0) pthread_join(th[k], NULL);
+    free(th); free(sl);
+    return started;
+}
+
 /* struct sizes, so the ctypes mirror in so100_oracle.py can be verified at load time */
 int so100o_sizeof(int which) {
     return which == 0 ? (int)sizeof(so100o_model) : which == 1 ? (int)sizeof(so100o_data) : (int)sizeof(so100o_env);

@@ -196,10 +196,14 @@ class OracleBatch:
         self.L.so100o_envs_step_range(C.byref(self.m), self.envs, begin, end, _fp(actions), int(autoreset),
                                       _fp(self.obs), _fp(self.rew), _fp(self.term), _fp(self.trunc), _fp(self.tobs))
 
-    def step(self, actions, threads=1, autoreset=True):
+    def step(self, actions, threads=1, autoreset=True, native_threads=False):
         actions = np.ascontiguousarray(actions, np.float32)
         if threads <= 1:
             self.step_range(actions, 0, self.n, autoreset)
+        elif native_threads:                                 # pthreads inside the C library: no per-slice Python dispatch (bench.py's all-core baseline)
+            rc = self.L.so100o_envs_step_threads(C.byref(self.m), self.envs, self.n, int(threads), _fp(actions), int(autoreset),
+                                                 _fp(self.obs), _fp(self.rew), _fp(self.term), _fp(self.trunc), _fp(self.tobs))
+            assert rc >= 0
         else:
             import concurrent.futures as cf
             if not hasattr(self, "_pool") or self._pool._max_workers != threads:
