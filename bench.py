@@ -96,9 +96,23 @@ def cpu_baseline(kind, flags, iters, seconds=10.0):
     from oracle import so100_oracle as O
     host = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))               # what this process can actually use (a cgroup / taskset may be narrower)
+        cores = len(os.sched_getaffinity(0))               # what this process can actually use (a taskset may be narrower) ...
     except AttributeError:
         cores = host
+    quota = None
+    try:                                                   # ... and what the container's CPU quota allows (cgroup v2 cpu.max / v1 cfs quota)
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q)/float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q/per
+        except Exception:
+            pass
+    if quota is not None and quota >= 1.0:
+        cores = max(1, min(cores, int(quota + 0.5)))
 
     def measure(threads, secs):
         n = 64 * threads
@@ -112,7 +126,7 @@ def cpu_baseline(kind, flags, iters, seconds=10.0):
         dt = time.perf_counter() - t0
         return n * steps / dt, n, steps, dt
     v, n, steps, dt = measure(cores, seconds)
-    out = {"value": v, "unit": "env-steps/s", "cores": cores, "host_cpus": host, "kind": "port",
+    out = {"value": v, "unit": "env-steps/s", "cores": cores, "host_cpus": host, "cpu_quota": quota, "kind": "port",
            "sample": f"{n} Env{kind:02d} envs x {steps} vec-steps ({dt:.1f} s), fp64 C oracle, {cores} threads (one per usable CPU) on a {host}-CPU host, same flags, "
                      + ("primal Newton to convergence" if iters < 0 else f"{iters} PGS sweeps")}
     if cores > 64:

@@ -19,6 +19,7 @@ REFP = O.F_REFERENCE                                       # friction + limits +
 C5 = O.F_CONTACT5
 NOPADS = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
 JS = np.float32(0.075)
+STEADY_MIN = 10          # envs (of 96) whose contact set is steady over the 16 substeps of the injected step; measured share printed by the test
 
 
 def _sim(*a, **k):
@@ -82,7 +83,9 @@ def test_pad_floor_step_vs_oracle(n):
             assert (cstat[i] & 255) == nmax
             worst_steady = max(worst_steady, eq, ev*1e-2)
         worst_any = max(worst_any, eq, ev*1e-2)
-    assert np.isfinite(gq).all() and np.isfinite(gv).all() and touched > 0.8*m and steady >= 10
+    print(f"[pad/floor 16-substep step, n={n}] envs {m}: touched {touched}, steady contact set over the 16 substeps {steady} (worst {worst_steady:.2e}), "
+          f"make / break inside the step {m - steady} (worst over all {worst_any:.2e}); max residual {res.max():.1e}")
+    assert np.isfinite(gq).all() and np.isfinite(gv).all() and touched > 0.8*m and steady >= STEADY_MIN
     assert (cstat >> 8).max() == 0 and res.max() < 1e-2      # nothing over the contact budget; the Newton solves converged
     assert worst_steady < 5e-6                               # steady contact set: angles 5e-6 rad, velocities 5e-4 rad/s
     assert worst_any < 2e-2                                  # a corner making / breaking contact one substep apart (see module docstring)
@@ -182,6 +185,8 @@ def test_pad_cube_grasp_vs_oracle(n):
             eq = max(np.abs(gq[i, :6] - O.arr(d.qpos)[:6]).max(), np.abs(gq[i, 6:9] - O.arr(d.qpos)[6:9]).max())
             ev = max(np.abs(gv[i, :6] - O.arr(d.qvel)[:6]).max(), np.abs(gv[i, 6:9] - O.arr(d.qvel)[6:9]).max())
             worst = max(worst, eq, ev*1e-2); compared += 1; coupled_steps += ncub > 0
+    print(f"[grasp 16-substep steps, n={n}] env-steps compared {compared} of {6*m} (an env leaves when its contact count differs from the oracle's), "
+          f"coupled {coupled_steps}, envs still compared after 6 steps {int(alive.sum())}; worst {worst:.2e}")
     assert compared > 2*m and coupled_steps > m//2
     assert worst < 2e-4                                      # 0.2 mm / 2e-4 rad, 2e-2 m/s / rad/s through the impact of the closing jaw on an 8 g cube
     # physics, not parity: after 6 steps (0.19 s; free fall would be 18 cm) the same share of cubes is still between the pads
@@ -291,6 +296,8 @@ def test_whole_env_steps_with_pad_contacts_vs_oracle(kind, flags):
                 alive[i] = False
             else:
                 worst[i] = max(worst[i], err)
+    print(f"[whole env steps, kind {kind} flags {flags}] envs {n}: touched {int(touched.sum())}, never separated from the oracle by a contact event {int(alive.sum())}, "
+          f"median / p90 error of those {np.median(worst[alive]):.2e} / {np.percentile(worst[alive], 90):.2e}")
     assert touched.mean() > (0.1 if kind == 1 else 0.5)      # the pads did reach the floor (Env01 starts high: fewer of its arms get there)
     assert alive.mean() > 0.6                                # most envs never saw a contact event a substep apart
     assert np.median(worst[alive]) < 2e-5 and np.percentile(worst[alive], 90) < 2e-4
