@@ -2,7 +2,9 @@
 rate (a) on a batch in which no arm is near the table (a constant lifting action: the contact Newton never runs), (b) on a batch in which EVERY arm
 starts within a few centimetres of / on the table and moves under random actions (what a compacted "contact-prone" sub-batch looks like), and (c) today's
 mixed batch from reset under random actions, with the share of envs whose pads are within MARGIN of the table.  Prediction for a split that sends the
-contact-prone share f to its own launch: 1 / ((1 - f) / r_a + f / r_b).
+contact-prone share f to its own launch: 1 / ((1 - f) / r_a + f / r_b).  (Round 3 BUILT that split -- a per-env "within 3 cm of the table" flag written at the
+end of every step, a compaction kernel, two launches of so100_step_fused -- and measured 0.155 -> 0.172 G at 5 % of the envs in contact, 0.100 G at 19 %: the
+compacted launch runs at rate (b), and with a 3 cm margin it receives a third of the batch.  Removed again; profiles/r03_large_batch_split_probe.txt.)
     python tools/kbench_split.py [envs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,7 +46,6 @@ print(f"(b) every arm at the table  : {rb:.3f} G env-steps/s, envs in contact {f
 # (c) today: from reset, random actions, arms settled
 sim = So100Sim(1, n, flags=F_REFERENCE, seed=3); sim.reset()
 rc, fc = rate(sim, rnd, 40, 20)
-q, _ = sim.get_state()
 print(f"(c) mixed batch (today)     : {rc:.3f} G env-steps/s, envs in contact {fc:.3f}")
 for f in (fc, 1.5*fc, 2*fc, 0.3):
     print(f"    split prediction with a contact-prone share of {f:.2f}: {1.0/((1 - f)/ra + f/rb):.3f} G env-steps/s")
