@@ -19,7 +19,7 @@ REFP = O.F_REFERENCE                                       # friction + limits +
 C5 = O.F_CONTACT5
 NOPADS = O.F_FRICTIONLOSS | O.F_LIMITS | O.F_FLOOR
 JS = np.float32(0.075)
-STEADY_MIN = 10          # envs (of 96) whose contact set is steady over the 16 substeps of the injected step; measured share printed by the test
+STEADY_MIN = 18          # envs (of 96) whose contact set is steady over the 16 substeps of the injected step (measured: 24; the test prints the classes)
 
 
 def _sim(*a, **k):
@@ -88,7 +88,10 @@ def test_pad_floor_step_vs_oracle(n):
     assert np.isfinite(gq).all() and np.isfinite(gv).all() and touched > 0.8*m and steady >= STEADY_MIN
     assert (cstat >> 8).max() == 0 and res.max() < 1e-2      # nothing over the contact budget; the Newton solves converged
     assert worst_steady < 5e-6                               # steady contact set: angles 5e-6 rad, velocities 5e-4 rad/s
-    assert worst_any < 2e-2                                  # a corner making / breaking contact one substep apart (see module docstring)
+    # EVERY env, also the 72 of 96 in which a corner makes / breaks contact inside the step: measured 3.6e-7 on all four kernels -- since round 3's
+    # solver rework fp32 and fp64 see these events in the same substep for this batch.  (2e-2 was round 2's bound for an event a substep apart;
+    # 2e-5 = the north star's 1e-5 relative at |q| ~ 2 rad keeps the test unconditional without demanding what the physics cannot promise.)
+    assert worst_any < 2e-5
 
 
 def test_pads_keep_the_gripper_above_the_floor_at_full_size():
@@ -187,8 +190,8 @@ def test_pad_cube_grasp_vs_oracle(n):
             worst = max(worst, eq, ev*1e-2); compared += 1; coupled_steps += ncub > 0
     print(f"[grasp 16-substep steps, n={n}] env-steps compared {compared} of {6*m} (an env leaves when its contact count differs from the oracle's), "
           f"coupled {coupled_steps}, envs still compared after 6 steps {int(alive.sum())}; worst {worst:.2e}")
-    assert compared > 2*m and coupled_steps > m//2
-    assert worst < 2e-4                                      # 0.2 mm / 2e-4 rad, 2e-2 m/s / rad/s through the impact of the closing jaw on an 8 g cube
+    assert compared >= 6*m - 6 and coupled_steps > m//2      # (measured: all 384 env-steps compared -- no env's contact count ever differed from the oracle's)
+    assert worst < 2e-5                                      # measured 3.4e-6: 2e-5 rad / m, 2e-3 per second through the impact of the closing jaw on an 8 g cube
     # physics, not parity: after 6 steps (0.19 s; free fall would be 18 cm) the same share of cubes is still between the pads
     # as in the oracle (Env01's ctrl = measured angle - 0.075 is a weak grip: tilted cubes slide out on both sides alike)
     held = (gq[:, 8] > qpos[:, 8] - 0.03).mean()
@@ -299,5 +302,5 @@ def test_whole_env_steps_with_pad_contacts_vs_oracle(kind, flags):
     print(f"[whole env steps, kind {kind} flags {flags}] envs {n}: touched {int(touched.sum())}, never separated from the oracle by a contact event {int(alive.sum())}, "
           f"median / p90 error of those {np.median(worst[alive]):.2e} / {np.percentile(worst[alive], 90):.2e}")
     assert touched.mean() > (0.1 if kind == 1 else 0.5)      # the pads did reach the floor (Env01 starts high: fewer of its arms get there)
-    assert alive.mean() > 0.6                                # most envs never saw a contact event a substep apart
-    assert np.median(worst[alive]) < 2e-5 and np.percentile(worst[alive], 90) < 2e-4
+    assert alive.mean() >= 0.9                               # (measured: 45-48 of 48 never saw a contact event a substep apart)
+    assert np.median(worst[alive]) < 1e-5 and np.percentile(worst[alive], 90) < 3e-5
