@@ -207,12 +207,12 @@ __global__ void __launch_bounds__(WG) so100_init_state(int n, float* state) {
 
 // Which step kernel for which batch (so100_create fills SimParams::mw_max from this; SO100_MW_MAX_ENVS in the environment overrides it
 // for measurements).  The 4-wave kernel so100_step_mw splits one env step over 4 waves: lowest latency, and it wins while the batch
-// leaves SIMDs idle (256 CUs x 64 envs = 16384).  Beyond that the one-wave kernel so100_step_fused has the higher throughput for the
-// variants whose substep fits the register file -- but the pad-contact variants need 1.0-1.5 KB of scratch per lane there (the contact
-// Newton next to the env state) while so100_step_mw<K, 23 | 55> runs with none, so for them the 4-wave kernel stays ahead at every batch
-// size measured (profiles/r03_large_batch_dispatch.txt).
+// leaves SIMDs idle (256 CUs x 64 envs = 16384).  Beyond that the one-wave kernel so100_step_fused has the higher throughput -- for the
+// contact variants too, although they carry 1.0-1.5 KB of scratch per lane there and so100_step_mw<K, 23 | 55> none: measured at 32 768 ...
+// 262 144 envs (profiles/r03_large_batch_dispatch.txt) the 4-wave kernel ties at 32 768 and loses 2x from 65 536 on, for every flag set.
+// One threshold for all; the two names are kept so that a future contact kernel can move its own.
 constexpr int MW_MAX_ENVS = 16384;
-constexpr int MW_MAX_ENVS_PADS = 16384;    // (provisional: set from the measurement)
+constexpr int MW_MAX_ENVS_PADS = 16384;
 inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
