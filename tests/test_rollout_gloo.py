@@ -22,7 +22,7 @@ def _worker(rank, world, port, n_local, T, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from oracle import so100_oracle as O
-        from so100_mujoco_rl_amd.rollout import RolloutChunk, gather_rollout, broadcast_policy, shard_range
+        from so100_mujoco_rl_amd.rollout import RolloutChunk, gather_rollout, broadcast_policy, shard_range, mean_over_ranks
         total = n_local * world
         lo, hi = shard_range(total, rank, world)
         assert hi - lo == n_local
@@ -62,6 +62,9 @@ def _worker(rank, world, port, n_local, T, q):
             assert [float(r[0, 0, 0]) for r in recv[0]] == [300.0 + k for k in range(world)]
         w = torch.full((4,), float(rank + 1)); broadcast_policy([w], src=0)
         assert torch.all(w == 1.0)
+        # the per-chunk statistic of the collector (mean env reward BEFORE the TimeLimit bootstrap) is averaged over the ranks, on every rank
+        mine = torch.tensor(float(10*rank + 1)); m = mean_over_ranks(mine)
+        assert float(m) == sum(10*k + 1 for k in range(world))/world and float(mine) == 10*rank + 1
         if rank == 0:
             q.put(("ok", full.numpy(), acts_all))
         else:
