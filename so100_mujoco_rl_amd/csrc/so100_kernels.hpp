@@ -150,6 +150,7 @@ __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     float obs[OD], tobs[OD]; bool term;
     const float reward = env_step_post<KIND>(e, ctx, u, P, cstale, obs, term);
     const StepResult r = env_step_finish<KIND>(e, reward, term, p, p.env_id_offset + (uint32_t)env, inj, io.start_tab, obs, tobs);
+    if constexpr (PADS) e.cload &= 0xFFFF;                         // (the per-launch count of physics_phase_mw is the persistent kernel's business)
     store_env_state<KIND, FL>(io.state, p.n, env, e);
 #pragma unroll
     for (int i = 0; i < OD; i++) io.obs[(size_t)env*OD + i] = obs[i];

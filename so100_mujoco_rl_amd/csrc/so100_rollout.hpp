@@ -366,6 +366,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
                 const int n0 = e.cstat & 255, dr = (e.cstat >> 8) + (code >> 16);
                 e.cstat = (nc > n0 ? nc : n0) | ((dr > 0xFFFF ? 0xFFFF : dr) << 8);
                 e.csig = nc > 0 ? __float_as_int(xa[14][lane]) : 0;
+                e.cload += nc > 0 ? 1 << 16 : 0;               // this launch's contact substeps ride in the upper half until the launch folds them in
             }
             arm_integrate<float>(e.q, e.v, e.qc, acc0, dq);
         }
@@ -795,6 +796,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
         if (wave == 3) prof_.flush_wg(wave, lane, e3, (lane % np) == 0 && e3 < p.n); else prof_.flush_wg(wave, lane, env, live);
     }
     if (wave == 0 && live) {
+        if constexpr (PADS) e.cload = ((e.cload & 0xFFFF) + (e.cload >> 16)) >> 1;       // contact load: average of its history and this launch's count
         store_env_state<KIND, FL>(state, p.n, env, e);
         if (ra.T > 0) {
 #pragma unroll

@@ -212,10 +212,10 @@ int so100_rollout(so100_sim* s, const so100_policy_weights* w, const so100_rollo
     PolicyWeights pw; memcpy(&pw, w, sizeof pw);
     RolloutArgs ra; ra.buf = io->rollout_dev; ra.T = T; ra.step_counter0 = step_counter0; ra.obs_in = io->obs_dev; ra.tobs_chunk = io->terminal_obs_chunk_dev;
     ra.slot_env = s->slot_env;
-    if (s->slot_env) {                                       // deal the envs that ended the last chunk in pad contact out over the workgroups
+    if (s->slot_env) {                                       // deal the envs out over the workgroups by their contact load
         const int nwg = (s->prm.n + s->prm.epw - 1)/s->prm.epw;
         hipLaunchKernelGGL(so100_build_slot_map, dim3(1), dim3(BALANCE_THREADS), 0, (hipStream_t)stream, s->prm.n, s->prm.epw, nwg,
-                           reinterpret_cast<const int32_t*>(s->state + (size_t)SF_contact_stat*(size_t)s->prm.n), s->slot_env);
+                           reinterpret_cast<const int32_t*>(s->state + (size_t)SF_contact_load*(size_t)s->prm.n), s->slot_env);
         HIP_TRY(hipGetLastError(), SO100_E_LAUNCH);
     }
     RolloutPtrs rp{ io->obs_dev, io->rew_dev, io->done_dev, io->trunc_dev, io->terminal_obs_dev, io->ep_return_dev, io->ep_length_dev };

@@ -53,6 +53,8 @@ struct EnvState {
     float aw[6];                // arm qacc of the previous substep: warm start of the pad-contact Newton (so100_contact.hpp)
     int   cstat;                // pad contacts: most contacts in a substep of the last env step | (dropped over the budget) << 8
     int   csig;                 // signature of the pad-contact SET of the last substep (so100_contact.hpp: contact_signature; 0 = no contact)
+    int   cload;                // contact load: running average (half-life one launch) of the substeps per persistent-rollout launch this env spent in
+                                // contact -- what so100_balance.hpp deals the envs out over the workgroups by; 0 after a reset
 };
 
 SO100_HD void idle_lane_state(EnvState& e) {
@@ -90,7 +92,7 @@ SO100_HD void idle_lane_state(EnvState& e) {
     X(av0, av[0], f, 3) X(av1, av[1], f, 3) X(av2, av[2], f, 3) X(av3, av[3], f, 3) X(av4, av[4], f, 3) X(av5, av[5], f, 3) \
     X(solver_residual, res, f, 4) \
     X(aw0, aw[0], f, 5) X(aw1, aw[1], f, 5) X(aw2, aw[2], f, 5) X(aw3, aw[3], f, 5) X(aw4, aw[4], f, 5) X(aw5, aw[5], f, 5) \
-    X(contact_stat, cstat, i, 5) X(contact_sig, csig, i, 5)
+    X(contact_stat, cstat, i, 5) X(contact_sig, csig, i, 5) X(contact_load, cload, i, 5)
 
 enum StateField : int {
 #define X(name, member, kind, group) SF_##name,
@@ -255,7 +257,7 @@ template <int KIND> SO100_HD void env_reset(EnvState& e, const float u[8], const
     // mj_resetData: qpos = qpos0, everything else (velocities, warm starts, applied forces, time, POSES) zero
 #pragma unroll
     for (int i = 0; i < 6; i++) { e.q[i] = 0.0f; e.v[i] = 0.0f; e.qc[i] = 0.0f; e.ff[i] = 0.0f; e.fl[i] = 0.0f; e.cube.vel[i] = 0.0f; e.cube.warm[i] = 0.0f; e.aw[i] = 0.0f; }
-    e.res = 0.0f; e.cstat = 0; e.csig = 0;
+    e.res = 0.0f; e.cstat = 0; e.csig = 0; e.cload = 0;
     e.cube.pos[0] = e.cube.pos[1] = e.cube.pos[2] = 0.0f;
     e.cube.quat[0] = 1.0f; e.cube.quat[1] = e.cube.quat[2] = e.cube.quat[3] = 0.0f;
     e.ee[0] = e.ee[1] = e.ee[2] = 0.0f; e.wrist_z = 0.0f; e.cx[0] = e.cx[1] = e.cx[2] = 0.0f;

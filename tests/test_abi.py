@@ -36,7 +36,7 @@ def test_metadata_calls(L):
     assert [L.so100_obs_dim(k) for k in (1, 2, 3, 4, 5, 6)] == [15, 15, 8, 8, 8, 15]
     assert L.so100_obs_dim(0) == -1 and L.so100_obs_dim(7) == -1
     n = L.so100_num_state_fields()
-    assert n == 97
+    assert n == 98
     assert L.so100_state_field_index(b"q0") == 0 and L.so100_state_field_index(b"cube_x") == 6
     assert L.so100_state_field_index(b"v0") == 13            # 13 qpos rows then 12 qvel rows: get/set_state rely on it
     assert L.so100_state_field_index(b"nope") == -1
