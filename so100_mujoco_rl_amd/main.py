@@ -8,7 +8,7 @@
 Same directory layout (models/ logs/ movies/), default model path models/{env}_{algo}/best_model.*, reward thresholds
 (6000 / 8000, ref: __init__.py:9,16) and checkpoint naming ({env}_{algo}_cp_*, ref: main.py:227-232).  Differences, all
 forced by the environment being a batched GPU simulator: N envs instead of 1; the learner is stable-baselines3 when it
-is importable and the built-in PPO (ppo.py, SB3-compatible state_dict) otherwise; `record` writes a state trajectory
+is importable and the built-in PPO (ppo.py) or DDPG (ddpg.py; ref: main.py:38-55), both with SB3-compatible state_dicts, otherwise; `record` writes a state trajectory
 (.npz) because there is no rasteriser (viewer / video are out of scope).
 """
 import logging
@@ -24,6 +24,7 @@ import torch.distributed as dist
 
 from .callbacks import EvalCallback, StopTrainingOnNoModelImprovement, StopTrainingOnRewardThreshold
 from .collector import RolloutCollector
+from .ddpg import DDPG, DDPGPolicy
 from .lib import F_REFERENCE
 from .ppo import PPO, ActorCritic
 from .rollout import broadcast_policy
@@ -47,19 +48,22 @@ def _default_model_path(environment, algorithm):
     return os.path.join(MODEL_DIR, f"{environment}_{algorithm}", "best_model.zip" if _have_sb3() else "best_model.pt")
 
 
-def _load_native(path, obs_dim, device):
-    net = ActorCritic(obs_dim).to(device)
+NATIVE_ALGORITHMS = ("PPO", "DDPG")
+
+
+def _load_native(path, obs_dim, device, algorithm="PPO"):
+    net = (DDPGPolicy(obs_dim) if algorithm == "DDPG" else ActorCritic(obs_dim)).to(device)
     net.load_state_dict(torch.load(path, map_location=device, weights_only=True))
     return net
 
 
 @click.group()
-@click.option("-a", "--algorithm", required=True, type=str, default="PPO", help="algorithm (PPO natively; any Stable-Baselines3 name when SB3 is installed)")
+@click.option("-a", "--algorithm", required=True, type=str, default="PPO", help="algorithm (PPO and DDPG natively; any Stable-Baselines3 name when SB3 is installed)")
 @click.option("-m", "--model", default=None, type=click.Path(exists=False), help="Path to model file")
 @click.pass_context
 def cli(ctx, algorithm, model):
-    if not _have_sb3() and algorithm != "PPO":
-        raise RuntimeError(f"algorithm {algorithm} needs stable-baselines3, which is not installed; the built-in learner is PPO")
+    if not _have_sb3() and algorithm not in NATIVE_ALGORITHMS:
+        raise RuntimeError(f"algorithm {algorithm} needs stable-baselines3, which is not installed; the built-in learners are {' and '.join(NATIVE_ALGORITHMS)}")
     ctx.ensure_object(dict)
     ctx.obj["ALGORITHM_NAME"] = algorithm
     ctx.obj["MODEL_PATH"] = model
@@ -104,6 +108,10 @@ def train(ctx, environment, envs, iters, seed):
         model.learn(total_timesteps=int(1e10) if iters == 0 else iters * 64 * envs, tb_log_name=f"{environment}_{algorithm}", callback=cb)
         model.save(os.path.join(save_dir, "best_model"))
         return
+    if algorithm == "DDPG":
+        if distributed:
+            raise RuntimeError("multi-GPU training uses the built-in PPO learner; DDPG runs on one GPU")
+        return _train_ddpg(env, environment, ctx.obj["MODEL_PATH"], save_dir, iters, seed, kind)
     learner = PPO(env.sim.obs_dim, env.device, seed=seed)
     if ctx.obj["MODEL_PATH"]:
         if not os.path.isfile(ctx.obj["MODEL_PATH"]):
@@ -165,6 +173,55 @@ def train(ctx, environment, envs, iters, seed):
         dist.barrier(); dist.destroy_process_group()
 
 
+def _train_ddpg(env, environment, model_path, save_dir, iters, seed, kind):
+    """The reference's DDPG branch (ref: main.py:38-55) on the built-in learner (ddpg.py): off-policy, one vector step at a time through
+    the tensor API; an "iter" is 64 vector steps (the PPO driver's chunk), evaluation / stop / checkpoint callbacks as in train()."""
+    learner = DDPG(env.sim.obs_dim, env.device, seed=seed, buffer_size=max(1_000_000, 16 * env.num_envs), gradient_steps=DDPG_GRADIENT_STEPS)
+    if model_path:
+        if not os.path.isfile(model_path):
+            raise RuntimeError(f"Model file {model_path} does not exist")
+        learner.net.load_state_dict(torch.load(model_path, map_location=env.device, weights_only=True))
+        logger.info(f"Model: starting with {model_path}")
+    else:
+        logger.info("Model: starting with new model")
+    threshold = K.REWARD_THRESHOLD[kind]
+    eval_env = So100VecEnv(environment, N_EVAL_EPISODES, device=env.device, flags=F_REFERENCE, seed=seed + 1000)
+    eval_cb = EvalCallback(lambda: _evaluate_actor(eval_env, learner.net.mean_action), lambda: torch.save(learner.net.state_dict(), os.path.join(save_dir, "best_model.pt")),
+                           EVAL_EVERY, on_new_best=StopTrainingOnRewardThreshold(threshold), after_eval=StopTrainingOnNoModelImprovement(5, 10000), log=logger.info)
+    obs, steps, it, t0 = None, 0, 0, time.time()
+    while True:
+        obs, stats = learner.learn_steps(env, 64, obs)
+        it += 1; steps += 64 * env.num_envs
+        if it % 10 == 0:
+            logger.info(f"iter {it:5d}  timesteps {steps/1e6:8.1f} M  reward/step {stats['mean_reward']:+.4f}  critic_loss {stats.get('critic_loss', float('nan')):.4f}  "
+                        f"updates {learner.n_updates}  fps {steps/(time.time()-t0)/1e6:.2f} M")
+        if not eval_cb.step():
+            logger.info(f"Stopping training: best evaluation reward {eval_cb.best_mean_reward:.1f} (threshold {threshold})"); break
+        if it % 40 == 0:
+            torch.save(learner.net.state_dict(), os.path.join(save_dir, f"{environment}_DDPG_cp__{steps}_steps.pt"))
+        if iters and it >= iters:
+            break
+    if eval_cb.n_evals == 0:
+        eval_cb.eval_every = 1; eval_cb.step()
+    torch.save(learner.net.state_dict(), os.path.join(save_dir, "last_model.pt"))
+    logger.info(f"done: {steps/1e6:.1f} M timesteps in {time.time()-t0:.1f} s; best evaluation reward {eval_cb.best_mean_reward:.1f} ({eval_cb.n_evals} evaluations); models in {save_dir}")
+
+
+@torch.no_grad()
+def _evaluate_actor(eval_env, act_fn):
+    """evaluate_policy(deterministic=True) through the stepwise tensor API (any policy: obs -> action): every env's first episode."""
+    obs = eval_env.reset_tensor()
+    n = eval_env.num_envs
+    ret = torch.zeros(n, device=eval_env.device); alive = torch.ones(n, dtype=torch.bool, device=eval_env.device)
+    for _ in range(eval_env.sim.cfg.max_episode_steps + 1):
+        obs, r, d, _tr = eval_env.step_tensor(act_fn(obs).clamp(-1, 1).contiguous())
+        ret += torch.where(alive, r, torch.zeros_like(ret)); alive &= ~d.bool()
+        if not bool(alive.any()):
+            break
+    return float(ret.mean().item())
+
+
+DDPG_GRADIENT_STEPS = 4   # updates of 256 per VECTOR step (SB3: 1 per step of ONE env; a vector step adds `envs` transitions, see ddpg.py)
 N_EVAL_EPISODES = 5       # SB3 EvalCallback's default n_eval_episodes (ref: main.py:217-224 passes none)
 EVAL_EVERY = 50           # updates between evaluations (an update is 64 x envs timesteps; the reference's eval_freq is 20 000 timesteps of one env)
 
@@ -201,7 +258,7 @@ def _rollout_policy(environment, algorithm, model_file, n, steps, show_io, show_
         policy = getattr(stable_baselines3, algorithm).load(model_file, device="cuda").policy
         act_fn = lambda o: policy._predict(o, deterministic=True)
     else:
-        net = _load_native(model_file, env.sim.obs_dim, env.device)
+        net = _load_native(model_file, env.sim.obs_dim, env.device, algorithm)
         act_fn = net.mean_action
     obs = env.reset_tensor()
     total = 0.0; traj = []

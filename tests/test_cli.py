@@ -88,3 +88,23 @@ def test_cli_train_distributed_code_path(tmp_path, monkeypatch):
     assert (tmp_path / "models" / "Env02-v1_PPO" / "last_model.pt").is_file()
     import torch.distributed as dist
     assert not dist.is_initialized()
+
+
+@pytest.mark.gpu
+def test_cli_ddpg_train_test(tmp_path, monkeypatch):
+    """The reference's DDPG branch (ref: main.py:38-55) on the built-in learner: train -> best / last / checkpoint files -> resume -> test."""
+    monkeypatch.chdir(tmp_path)
+    run = CliRunner()
+    r = run.invoke(drv.cli, ["-a", "DDPG", "train", "-e", "Env01-v1", "--envs", "256", "--iters", "40"], catch_exceptions=False)
+    assert r.exit_code == 0
+    d = tmp_path / "models" / "Env01-v1_DDPG"
+    assert (d / "best_model.pt").is_file() and (d / "last_model.pt").is_file()
+    assert any(f.name.startswith("Env01-v1_DDPG_cp_") for f in d.iterdir())
+    import torch
+    sd = torch.load(d / "last_model.pt", weights_only=True)
+    assert tuple(sd["actor.mu.0.weight"].shape) == (300, 15) and tuple(sd["critic.qf0.0.weight"].shape) == (200, 21)
+    assert all(torch.isfinite(v).all() for v in sd.values())
+    r = run.invoke(drv.cli, ["-a", "DDPG", "test", "-e", "Env01-v1", "--envs", "64", "--steps", "64", "--show-io"], catch_exceptions=False)
+    assert r.exit_code == 0
+    r = run.invoke(drv.cli, ["-a", "DDPG", "-m", str(d / "last_model.pt"), "train", "-e", "Env01-v1", "--envs", "128", "--iters", "1"], catch_exceptions=False)
+    assert r.exit_code == 0
