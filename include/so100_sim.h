@@ -48,12 +48,17 @@ extern "C" {
 #define SO100_F_LINKS_FLOOR 64u   /* capsule proxies of the arm links' collision MESHES (so_arm100_camera.xml:58-59, 85, 92, 99, 106-107, 117-119: the STL files
                                      are not in the reference snapshot) vs the floor: one capsule per link 1..5, built by rule from the link frames and
                                      inertial boxes (csrc/so100_model_def.h).  A documented STAND-IN, not reference geometry; off in SO100_F_REFERENCE */
+#define SO100_F_LINKS_CUBE 128u   /* the same kind of capsule on Rotation_Pitch and Upper_Arm vs the cube: the two arm bodies the reference scene does NOT exclude from
+                                     colliding with block_a (env01.xml:44-48).  Stand-in geometry and a stand-in capsule-box narrowphase
+                                     (oracle/so100_oracle.c: so100o_capsule_box); needs a dynamic cube; off in SO100_F_REFERENCE                        */
 /* what the reference scene simulates, as far as it can be reproduced: the arm's mesh geoms (class "collision",
  * so_arm100_camera.xml:58-59) are not in the reference snapshot, so link-vs-floor / link-vs-link mesh contacts are absent */
 #define SO100_F_REFERENCE (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_PADS_FLOOR)
 #define SO100_F_NOPADS    (SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR)   /* round-1 "reference": no arm contact at all */
 #define SO100_F_CONTACT5  (SO100_F_REFERENCE | SO100_F_PADS_CUBE)                   /* BASELINE.json configs[4]                   */
 #define SO100_F_REFERENCE_LINKS (SO100_F_REFERENCE | SO100_F_LINKS_FLOOR)           /* + the link proxies: no arm link passes through the table */
+#define SO100_F_REFERENCE_PROXIES (SO100_F_REFERENCE_LINKS | SO100_F_LINKS_CUBE)    /* + Rotation_Pitch / Upper_Arm vs the cube: every contact pair of the reference scene
+                                                                                        that does not need two mesh shapes (link vs link stays out) */
 
 #define SO100_E_INVALID  (-1)     /* bad argument                                   */
 #define SO100_E_NODEVICE (-2)     /* no usable HIP device / HIP runtime failure      */

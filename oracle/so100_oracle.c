@@ -179,6 +179,17 @@ void so100o_model_init(so100o_model* m) {
         if (l >= 4 && r > SO100_PROX_JAW_RADIUS_MAX) r = SO100_PROX_JAW_RADIUS_MAX;
         m->prox_radius[k] = r;
     }
+    /* the same rule on links 0 (Rotation_Pitch) and 1 (Upper_Arm), against the cube (SO100O_F_LINKS_CUBE; scene:44-48 excludes every other arm body) */
+    for (int k = 0; k < SO100O_NCPROX; k++) {
+        const int l = k;
+        m->cprox_body[k] = l + 2;
+        memset(m->cprox_p[k], 0, sizeof m->cprox_p[k]);
+        memcpy(m->cprox_p[k][1], SO100_LINK_POS[l + 1], sizeof(double)*3);
+        const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+        double h[3] = { 0.5*sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
+        const double hmax = fmax(h[0], fmax(h[1], h[2]));
+        m->cprox_radius[k] = 0.5*(h[0] + h[1] + h[2] - hmax);
+    }
 
     /* mj_setConst: dof_M0, dof_invweight0, body_invweight0 at qpos0, then kv from dampratio */
     so100o_data* d = (so100o_data*)calloc(1, sizeof *d);
@@ -643,6 +654,65 @@ int so100o_box_box(const double cA[3], const double RA[9], const double hA[3], c
     return cnt;
 }
 
+/* Capsule (segment a..b, radius r; geom1) against a box (centre c, rotation R row-major world <- box, half sizes h; geom2): a STAND-IN for
+ * mjc_CapsuleBox, like the capsules themselves.  The point of the segment nearest to the box minimises f(t) = dist^2(a + t (b - a), box) over
+ * [0, 1], a convex piecewise-quadratic function: f' is non-decreasing and LINEAR between the (at most six) parameters at which a coordinate
+ * of the point crosses a face plane.  f' is evaluated at those and at the two ends; the root lies between the last candidate with f' < 0
+ * and the first with f' >= 0, by linear interpolation -- exact, no iteration.  Then a sphere-box test at that point.  One contact: position
+ * midway between the two surfaces, normal from the capsule to the box.  Returns 0 / 1. */
+static double capsule_box_slope(const double la[3], const double d[3], const double h[3], double t) {
+    double g = 0;
+    for (int k = 0; k < 3; k++) { const double sk = la[k] + t*d[k]; g += (sk - fmin(fmax(sk, -h[k]), h[k]))*d[k]; }
+    return g;
+}
+int so100o_capsule_box(const double a[3], const double b[3], double r, const double c[3], const double R[9], const double h[3],
+                       double pos[3], double normal[3], double* dist) {
+    double la[3], d[3], s[3], q[3], e[3], tj[8], gj[8];
+    for (int k = 0; k < 3; k++) {                          /* box frame: local = R' (world - c) */
+        la[k] = R[k]*(a[0] - c[0]) + R[3 + k]*(a[1] - c[1]) + R[6 + k]*(a[2] - c[2]);
+        d[k] = R[k]*(b[0] - a[0]) + R[3 + k]*(b[1] - a[1]) + R[6 + k]*(b[2] - a[2]);
+    }
+    tj[0] = 0.0; tj[1] = 1.0;
+    for (int k = 0; k < 3; k++) {
+        const double inv = fabs(d[k]) > 1e-12 ? 1.0/d[k] : 0.0;      /* (a coordinate that does not move crosses no plane: candidate 0 again) */
+        tj[2 + 2*k] = fmin(fmax((-h[k] - la[k])*inv, 0.0), 1.0); tj[3 + 2*k] = fmin(fmax((h[k] - la[k])*inv, 0.0), 1.0);
+    }
+    for (int j = 0; j < 8; j++) gj[j] = capsule_box_slope(la, d, h, tj[j]);
+    double thi = 2.0, ghi = 0.0, tlo = -1.0, glo = 0.0;
+    for (int j = 0; j < 8; j++) if (gj[j] >= 0 && tj[j] < thi) { thi = tj[j]; ghi = gj[j]; }
+    if (thi > 1.5) { thi = 1.0; ghi = 0.0; }               /* f' < 0 on the whole segment: the far end */
+    for (int j = 0; j < 8; j++) if (gj[j] < 0 && tj[j] <= thi && tj[j] > tlo) { tlo = tj[j]; glo = gj[j]; }
+    double t = thi;
+    if (tlo >= 0.0 && ghi > 0) t = tlo - glo*(thi - tlo)/(ghi - glo);
+    /* the axis itself passes through the box (f = 0 on an interval, found by the slab test): the middle of that interval */
+    double tin = 0.0, tout = 1.0;
+    for (int k = 0; k < 3; k++) {
+        if (fabs(d[k]) > 1e-12) {
+            const double t1 = (-h[k] - la[k])/d[k], t2 = (h[k] - la[k])/d[k];
+            tin = fmax(tin, fmin(t1, t2)); tout = fmin(tout, fmax(t1, t2));
+        } else if (fabs(la[k]) > h[k]) tin = 2.0;
+    }
+    if (tin <= tout) t = 0.5*(tin + tout);
+    for (int k = 0; k < 3; k++) { s[k] = la[k] + t*d[k]; q[k] = fmin(fmax(s[k], -h[k]), h[k]); e[k] = s[k] - q[k]; }
+    const double len = sqrt(dot3(e, e));
+    double n[3] = { 0, 0, 0 }, dst;
+    if (len > 1e-9) { for (int k = 0; k < 3; k++) n[k] = e[k]/len; dst = len - r; }
+    else {                                                  /* the axis point is inside the box: leave through the nearest face */
+        int ax = 0; double best = h[0] - fabs(s[0]);
+        for (int k = 1; k < 3; k++) if (h[k] - fabs(s[k]) < best) { best = h[k] - fabs(s[k]); ax = k; }
+        n[ax] = s[ax] < 0 ? -1.0 : 1.0; q[ax] = n[ax]*h[ax]; dst = -best - r;
+    }
+    if (dst > 0) return 0;
+    double pl[3];
+    for (int k = 0; k < 3; k++) pl[k] = q[k] + 0.5*dst*n[k];
+    for (int k = 0; k < 3; k++) {
+        pos[k] = c[k] + R[3*k]*pl[0] + R[3*k + 1]*pl[1] + R[3*k + 2]*pl[2];
+        normal[k] = -(R[3*k]*n[0] + R[3*k + 1]*n[1] + R[3*k + 2]*n[2]);
+    }
+    *dist = dst;
+    return 1;
+}
+
 /* point Jacobian row of body b at world point p along direction dir, accumulated into J with sign sg */
 static void jac_point_dir(const so100o_data* d, int b, const double p[3], const double dir[3], double sg, double* J) {
     if (b <= 1) return;                                     /* world / welded base */
@@ -767,6 +837,20 @@ static void make_constraints(const so100o_model* m, so100o_data* d, unsigned fla
                 const double pos[3] = { c[0], c[1], c[2] - m->prox_radius[k] - 0.5*dist };
                 add_contact(m, d, 3, k, 144 + 2*k + e, 0, b, pos, nz, dist, mu, ref, imp);
             }
+        }
+    }
+    if ((flags & SO100O_F_LINKS_CUBE) && !(flags & SO100O_F_CUBE_PINNED)) {          /* Q7: Rotation_Pitch / Upper_Arm vs block_a (scene:44-48 excludes the rest) */
+        double ref[2], imp[5], mu, hs[3] = { SO100_CUBE_HALF, SO100_CUBE_HALF, SO100_CUBE_HALF };
+        mix_contact_params(m->def_solref, m->def_solimp, m->def_friction, m->def_solref, m->def_solimp, m->def_friction, ref, imp, &mu);
+        for (int k = 0; k < SO100O_NCPROX; k++) {
+            const int b = m->cprox_body[k];
+            double e[2][3], v[3], pos[3], nrm[3], dist;
+            for (int j = 0; j < 2; j++) {
+                mat_vec3(v, d->xmat[b], m->cprox_p[k][j]);
+                for (int a = 0; a < 3; a++) e[j][a] = d->xpos[b][a] + v[a];
+            }
+            if (so100o_capsule_box(e[0], e[1], m->cprox_radius[k], d->xpos[CUBE], d->xmat[CUBE], hs, pos, nrm, &dist))
+                add_contact(m, d, 4, k, 160 + k, b, CUBE, pos, nrm, dist, mu, ref, imp);
         }
     }
 }

@@ -9,8 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-NB, NQ, NV, MAXEFC, NINJECT, NPAD, MAXCON, NPROX = 9, 13, 12, 412, 16, 8, 100, 5
-F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE, F_LINKS_FLOOR = 1, 2, 4, 8, 16, 32, 64
+NB, NQ, NV, MAXEFC, NINJECT, NPAD, MAXCON, NPROX, NCPROX = 9, 13, 12, 412, 16, 8, 100, 5, 2
+F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE, F_LINKS_FLOOR, F_LINKS_CUBE = 1, 2, 4, 8, 16, 32, 64, 128
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR | F_PADS_FLOOR        # what the reference scene simulates (minus the mesh geoms)
 F_CONTACT5 = F_REFERENCE | F_PADS_CUBE                                   # BASELINE.json configs[4]
 
@@ -37,6 +37,7 @@ class Model(C.Structure):
         ("def_solref", d_ * 2), ("def_solimp", d_ * 5), ("def_friction", d_),
         ("max_contacts", C.c_int),
         ("prox_body", C.c_int * NPROX), ("prox_p", d_ * 3 * 2 * NPROX), ("prox_radius", d_ * NPROX),
+        ("cprox_body", C.c_int * NCPROX), ("cprox_p", d_ * 3 * 2 * NCPROX), ("cprox_radius", d_ * NCPROX),
     ]
 
 

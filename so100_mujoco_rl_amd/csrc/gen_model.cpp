@@ -215,6 +215,18 @@ int main(int argc, char** argv) {
         std::fprintf(f, "static constexpr int PROX_LINK[%d] = { %d, %d, %d, %d, %d };\n", SO100_NPROX, SO100_PROX_LINK[0], SO100_PROX_LINK[1], SO100_PROX_LINK[2], SO100_PROX_LINK[3], SO100_PROX_LINK[4]);
         emit(f, "PROX_FAR", &far_[0][0], SO100_NPROX, 3);
         emit1(f, "PROX_RADIUS", rad, SO100_NPROX);
+        // link / cube proxies (F_LINKS_CUBE): capsule k on link k (0 Rotation_Pitch, 1 Upper_Arm), same rule
+        double cfar[SO100_NCPROX][3], crad[SO100_NCPROX];
+        for (int k = 0; k < SO100_NCPROX; k++) {
+            for (int a = 0; a < 3; a++) cfar[k][a] = SO100_LINK_POS[k + 1][a];
+            const double* I = SO100_LINK_DIAGINERTIA[k]; const double mass = SO100_LINK_MASS[k];
+            const double h[3] = { 0.5*std::sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*std::sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*std::sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
+            crad[k] = 0.5*(h[0] + h[1] + h[2] - std::fmax(h[0], std::fmax(h[1], h[2])));
+        }
+        std::fprintf(f, "// link / cube proxies (F_LINKS_CUBE): capsule k on link k (Rotation_Pitch, Upper_Arm), from that link's joint origin to its child's (CPROX_FAR[k], link coordinates)\n");
+        std::fprintf(f, "static constexpr int NCPROX = %d;\n", SO100_NCPROX);
+        emit(f, "CPROX_FAR", &cfar[0][0], SO100_NCPROX, 3);
+        emit1(f, "CPROX_RADIUS", crad, SO100_NCPROX);
     }
     std::fprintf(f, "}  // namespace so100g\n");
     std::fclose(f);

@@ -42,8 +42,10 @@
 
 namespace so100 {
 
-enum : unsigned { F_PADS_FLOOR = 16u, F_PADS_CUBE = 32u, F_LINKS_FLOOR = 64u };
-constexpr unsigned F_ANY_CONTACT = F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR;      // any of these: the contact store / contact wave / primal solve are in play
+enum : unsigned { F_PADS_FLOOR = 16u, F_PADS_CUBE = 32u, F_LINKS_FLOOR = 64u, F_LINKS_CUBE = 128u };
+constexpr unsigned F_ANY_CONTACT = F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR | F_LINKS_CUBE;
+constexpr unsigned F_ARM_CUBE = F_PADS_CUBE | F_LINKS_CUBE;                      // pairs that couple the arm's solve with the cube's
+constexpr unsigned F_ANY_LINKS = F_LINKS_FLOOR | F_LINKS_CUBE;                   // records on links other than the jaws: the solver's general form      // any of these: the contact store / contact wave / primal solve are in play
 
 constexpr int MAXPADC = 16;                  // budget of PAD contacts per env (oracle: model.max_contacts); detection order = pad/floor
                                              // by pad, then pad/cube by pad; further ones are dropped and counted
@@ -53,14 +55,15 @@ enum { C_PX = 0, C_PY, C_PZ, C_NX, C_NY, C_NZ, C_KD, C_RINV, C_KIND, C_VX, C_VY,
 // C_P point (world, midway between the surfaces), C_N normal geom1 -> geom2 (the tangents follow from it: mju_makeFrame),
 // C_KD = K imp dist, C_RINV = 1/R of the 4 edge rows, C_V = B * relative point velocity (the velocity part of -aref),
 // C_KIND: kind | id << 3 | mask0 << 11 (an integer held in a float) -- kind: 0 cube/floor, 1 / 2 pad/floor on link 4 / 5, 3 / 4 pad/cube
-// with the pad on link 4 / 5, 5 link proxy/floor (F_LINKS_FLOOR; id = 144 + 2 proxy + capsule end, on link proxy + 1); id: which geometric feature made the contact (pad corner, manifold slot: stable from substep to substep);
+// with the pad on link 4 / 5, 5 link proxy/floor (F_LINKS_FLOOR; id = 144 + 2 proxy + capsule end, on link proxy + 1), 6 link proxy/cube (F_LINKS_CUBE; id = 160 + link, link 0 / 1); id: which geometric feature made the contact (pad corner, manifold slot: stable from substep to substep);
 // mask0: the pyramid edges that carried force at the end of the previous substep's solve (the Newton's first guess of the active set).
 // The solver leaves (hash(id) << 4 | final mask), one byte, of every record in the store's "previous" list for the next substep's
 // detection (4-bit hash: distinct for the same corner of different pads; a collision only costs a worse first guess).
 SO100_HD int contact_id_hash(int id) { return (id ^ (id >> 4)) & 15; }
 // the arm link (0..5) that carries the record's arm-side geom (kind != 0)
 static_assert(so100g::NPROX == 5 && so100g::PROX_LINK[0] == 1 && so100g::PROX_LINK[4] == 5, "proxy k sits on link k + 1");
-SO100_HD int contact_link(int kind, int id) { return kind == 5 ? ((id - 144) >> 1) + 1 : ((kind == 2 || kind == 4) ? 5 : 4); }
+SO100_HD int contact_link(int kind, int id) { return kind == 5 ? ((id - 144) >> 1) + 1 : kind == 6 ? id - 160 : ((kind == 2 || kind == 4) ? 5 : 4); }
+SO100_HD bool contact_on_cube(int kind) { return kind == 3 || kind == 4 || kind == 6; }      // arm geom (geom1) against the cube (geom2)
 // 32-bit mix of a feature id; a contact SET's signature is the wrapping sum of it over the set's PAD contacts (order-free: the
 // cooperating lanes add their shares).  Parity tests compare it with the same sum over the oracle's contact list (so100o_contact.feat).
 SO100_HD int contact_id_mix(int id) {
@@ -221,6 +224,9 @@ SO100_HD void contact_put(Store& cs, int s, int kind, int id, const T p[3], cons
         const int l = contact_link(kind, id);
         tran = l == 1 ? T(so100g::LINK_INVWEIGHT_TRAN[1]) : l == 2 ? T(so100g::LINK_INVWEIGHT_TRAN[2]) : l == 3 ? T(so100g::LINK_INVWEIGHT_TRAN[3])
              : l == 4 ? T(so100g::LINK_INVWEIGHT_TRAN[4]) : T(so100g::LINK_INVWEIGHT_TRAN[5]);
+    } else if (kind == 6) {                                    // link proxy / cube: default parameters on both sides
+        imp = impedance(tabs(dist)); K = T(so100g::SOLREF_K); B = T(so100g::SOLREF_B);
+        tran = (contact_link(kind, id) == 0 ? T(so100g::LINK_INVWEIGHT_TRAN[0]) : T(so100g::LINK_INVWEIGHT_TRAN[1])) + T(1.0/so100g::CUBE_MASS);
     } else {
         imp = impedance_pad(tabs(dist)); K = T(so100g::PADC_K); B = T(so100g::PADC_B);
         tran = (kind == 1 || kind == 3) ? T(so100g::LINK_INVWEIGHT_TRAN[4]) : T(so100g::LINK_INVWEIGHT_TRAN[5]);
@@ -437,6 +443,72 @@ SO100_HD int box_box(const T cA[3], const T RA[9], const T hA[3], const T cB[3],
         }
     }
     return cnt;
+}
+
+// Capsule (segment a..b, radius r: geom1) against a box (geom2): the stand-in narrowphase of oracle/so100_oracle.c: so100o_capsule_box, same
+// operations in the same order.  The segment's point nearest to the box minimises a convex piecewise-quadratic function of the segment parameter t
+// whose derivative is linear between the <= 6 parameters at which a coordinate crosses a face plane: evaluate it at those and at the ends,
+// interpolate in the piece that holds the root (exact, no iteration), then a sphere-box test there.  One contact, normal capsule -> box.  Returns 0 / 1.
+template <typename T>
+SO100_HD int capsule_box(const T a[3], const T b[3], T r, const T c[3], const T R[9], const T h[3], T pos[3], T nrm[3], T& dist) {
+    T la[3], d[3], s[3], q[3], e[3], tj[8], gj[8];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        la[k] = R[k]*(a[0] - c[0]) + R[3 + k]*(a[1] - c[1]) + R[6 + k]*(a[2] - c[2]);
+        d[k] = R[k]*(b[0] - a[0]) + R[3 + k]*(b[1] - a[1]) + R[6 + k]*(b[2] - a[2]);
+    }
+    tj[0] = T(0); tj[1] = T(1);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const T inv = tabs(d[k]) > T(1e-12) ? T(1)/d[k] : T(0);
+        tj[2 + 2*k] = tclamp((-h[k] - la[k])*inv, T(0), T(1)); tj[3 + 2*k] = tclamp((h[k] - la[k])*inv, T(0), T(1));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        T g = T(0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const T sk = la[k] + tj[j]*d[k]; g += (sk - tclamp(sk, -h[k], h[k]))*d[k]; }
+        gj[j] = g;
+    }
+    T thi = T(2), ghi = T(0), tlo = T(-1), glo = T(0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (gj[j] >= T(0) && tj[j] < thi) { thi = tj[j]; ghi = gj[j]; }
+    if (thi > T(1.5)) { thi = T(1); ghi = T(0); }
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (gj[j] < T(0) && tj[j] <= thi && tj[j] > tlo) { tlo = tj[j]; glo = gj[j]; }
+    T t = thi;
+    if (tlo >= T(0) && ghi > T(0)) t = tlo - glo*(thi - tlo)/(ghi - glo);
+    T tin = T(0), tout = T(1);                                 // the axis itself passes through the box (slab test): the middle of that interval
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (tabs(d[k]) > T(1e-12)) {
+            const T t1 = (-h[k] - la[k])/d[k], t2 = (h[k] - la[k])/d[k];
+            tin = tmax(tin, tmin(t1, t2)); tout = tmin(tout, tmax(t1, t2));
+        } else if (tabs(la[k]) > h[k]) tin = T(2);
+    }
+    if (tin <= tout) t = T(0.5)*(tin + tout);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { s[k] = la[k] + t*d[k]; q[k] = tclamp(s[k], -h[k], h[k]); e[k] = s[k] - q[k]; }
+    const T len = tsqrt(dot(e, e));
+    T n[3] = { T(0), T(0), T(0) }, dst;
+    if (len > T(1e-9)) { const T rl = trcp(len); n[0] = e[0]*rl; n[1] = e[1]*rl; n[2] = e[2]*rl; dst = len - r; }
+    else {
+        int ax = 0; T best = h[0] - tabs(s[0]);
+#pragma unroll
+        for (int k = 1; k < 3; k++) if (h[k] - tabs(s[k]) < best) { best = h[k] - tabs(s[k]); ax = k; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (k == ax) { n[k] = s[k] < T(0) ? T(-1) : T(1); q[k] = n[k]*h[k]; }
+        dst = -best - r;
+    }
+    if (dst > T(0)) return 0;
+    const T pl[3] = { q[0] + T(0.5)*dst*n[0], q[1] + T(0.5)*dst*n[1], q[2] + T(0.5)*dst*n[2] };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        pos[k] = c[k] + R[3*k]*pl[0] + R[3*k + 1]*pl[1] + R[3*k + 2]*pl[2];
+        nrm[k] = -(R[3*k]*n[0] + R[3*k + 1]*n[1] + R[3*k + 2]*n[2]);
+    }
+    dist = dst;
+    return 1;
 }
 
 // The box (in jaw coordinates) that encloses all pads of one jaw link: centre and half sizes, compile-time from the pad table.
@@ -668,6 +740,33 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
             }
         }
     }
+    if ((flags & F_LINKS_CUBE) != 0u && cube_live && serial_lane) {
+        // Q7: the capsules of Rotation_Pitch (joint origin 0 -> 1) and Upper_Arm (1 -> 2) against the cube; stand-in narrowphase capsule_box
+#pragma unroll 1
+        for (int k = 0; k < so100g::NCPROX; k++) {
+            T a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { a[i] = k == 0 ? W.o[0][i] : W.o[1][i]; b[i] = k == 0 ? W.o[1][i] : W.o[2][i]; }
+            const T r = k == 0 ? T(so100g::CPROX_RADIUS[0]) : T(so100g::CPROX_RADIUS[1]);
+            // bounding spheres: segment midpoint / half length + radius against the cube's circumsphere
+            const T mx = T(0.5)*(a[0] + b[0]) - cube.pos[0], my = T(0.5)*(a[1] + b[1]) - cube.pos[1], mz = T(0.5)*(a[2] + b[2]) - cube.pos[2];
+            const T hl2 = T(0.25)*((b[0] - a[0])*(b[0] - a[0]) + (b[1] - a[1])*(b[1] - a[1]) + (b[2] - a[2])*(b[2] - a[2]));
+            const T reach = tsqrt(hl2) + r + T(so100g::CUBE_HALF*1.7320508075688772);
+            if (mx*mx + my*my + mz*mz >= reach*reach) continue;
+            T p[3], nrm[3], dist;
+            if (capsule_box<T>(a, b, r, cube.pos, Rc, hc, p, nrm, dist) == 0) continue;
+            T va[3] = { T(0), T(0), T(0) }, vc[3];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                T col[3]; cross(W.z[i], p, col);
+                const T vi = i <= k ? v[i] : T(0);
+                va[0] += vi*(col[0] + W.oz[i][0]); va[1] += vi*(col[1] + W.oz[i][1]); va[2] += vi*(col[2] + W.oz[i][2]);
+            }
+            cube_point_motion(Rc, cube.pos, cube.vel, p, vc);
+            const T vr[3] = { vc[0] - va[0], vc[1] - va[1], vc[2] - va[2] };
+            if (contact_add(cs, 6, 160 + k, p, nrm, dist, vr)) coupled = true;
+        }
+    }
     if (coupled && serial_lane && (flags & F_FLOOR) != 0u) {
         plane_box<T>(cube.pos, Rc, hc, [&](const T* p, T dist, int corner) {
             T vr[3]; cube_point_motion(Rc, cube.pos, cube.vel, p, vr);
@@ -675,7 +774,7 @@ SO100_HD bool detect_pad_contacts(const WorldFK<T>& W, const T v[6], const Cube<
         });
     }
     if constexpr (Store::COOP) {
-        if (cs.nparts > 1 && (flags & (F_PADS_CUBE | F_LINKS_FLOOR)) != 0u) {   // what the first lane appended is the group's
+        if (cs.nparts > 1 && (flags & (F_PADS_CUBE | F_ANY_LINKS)) != 0u) {   // what the first lane appended is the group's
             cs.n = coop_first(cs, cs.n); cs.dropped = coop_first(cs, cs.dropped); coupled = coop_first(cs, coupled ? 1 : 0) != 0;
         }
     }
@@ -777,8 +876,8 @@ template <int ND, typename T, class Store, bool LINKS = false> struct PrimalProb
             // n = e_z, t1 = e_y, t2 = -e_x): projections on the frame are component picks
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
             if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
-            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind == 3 || kind == 4);
-            const T sgn = (ND == 12 && (kind == 3 || kind == 4)) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube pairs, geom2 in floor pairs
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || contact_on_cube(kind));
+            const T sgn = (ND == 12 && contact_on_cube(kind)) ? T(-1) : T(1);   // the arm link is geom1 in pad/cube and link/cube pairs, geom2 in floor pairs
             const int link = LINKS ? contact_link(kind, (code >> 3) & 255) : (on5 ? 5 : 4);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) };
             T col[6][3];                                        // LINKS: column i of the point Jacobian, zero where joint i does not move the point
@@ -975,8 +1074,8 @@ template <int ND, typename T, class Store, bool LINKS = false> struct PrimalProb
             const int code = (int)cs.get(s, C_KIND), kind = code & 7;
             T n[3] = { T(0), T(0), T(1) }, t1[3] = { T(0), T(1), T(0) }, t2[3] = { T(-1), T(0), T(0) };
             if (ND == 12) { n[0] = cs.get(s, C_NX); n[1] = cs.get(s, C_NY); n[2] = cs.get(s, C_NZ); contact_frame(n, t1, t2); }
-            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || kind == 3 || kind == 4);
-            const T sgn = (ND == 12 && (kind == 3 || kind == 4)) ? T(-1) : T(1);
+            const bool on5 = kind == 2 || kind == 4, arm_side = ND == 6 || kind != 0, cube_side = ND == 12 && (kind == 0 || contact_on_cube(kind));
+            const T sgn = (ND == 12 && contact_on_cube(kind)) ? T(-1) : T(1);
             T w[3] = { cs.get(s, C_VX), cs.get(s, C_VY), cs.get(s, C_VZ) }, wd[3] = { T(0), T(0), T(0) };
             if (LINKS) {
                 const int link = contact_link(kind, (code >> 3) & 255);
@@ -1345,7 +1444,7 @@ SO100_HD void contact_solve_integrate(T q[6], T v[6], T qc[6], const T ctrl[6], 
     ldl6_reconstruct(A.M, Marm);
 #pragma unroll
     for (int i = 0; i < 6; i++) acc[i] = aw[i];
-    const T res = (flags & F_LINKS_FLOOR) != 0u ? contact_solve<true>(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones)
+    const T res = (flags & F_ANY_LINKS) != 0u ? contact_solve<true>(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones)
                                                 : contact_solve<false>(tau, r, Marm, W, cs, coupled, cube.pos, cube.warm, Rc, applied, iters, acc, xcube, zones);
     if (coupled) {
         // the cube: warm start memory (x - qacc_smooth, the convention of so100_cube.hpp) and semi-implicit Euler

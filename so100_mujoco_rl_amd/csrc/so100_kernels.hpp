@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(WG, ((FL == (int)SO100_F_CUBE_PINNED && reach_
 template <int KIND, int FL>
 __global__ void __launch_bounds__(256) so100_step_mw(SimParams p, StepPtrs io) {
     constexpr bool PADS = FL < 0 || (FL & (int)F_ANY_CONTACT) != 0;
-    constexpr bool LINKS = FL < 0 || (FL & (int)F_LINKS_FLOOR) != 0;
+    constexpr bool LINKS = FL < 0 || (FL & (int)F_ANY_LINKS) != 0;
     __shared__ float xq[PADS ? 24 : 18][64];
     __shared__ float xc[24][64];
     __shared__ float xb[6][64];
@@ -214,7 +214,7 @@ __global__ void __launch_bounds__(WG) so100_init_state(int n, float* state) {
 // One threshold for all; the two names are kept so that a future contact kernel can move its own.
 constexpr int MW_MAX_ENVS = 16384;
 constexpr int MW_MAX_ENVS_PADS = 16384;
-inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
+inline int mw_max_envs_for(unsigned flags) { return (flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR | SO100_F_LINKS_CUBE)) ? MW_MAX_ENVS_PADS : MW_MAX_ENVS; }
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + WG - 1)/WG)); }
 
 struct RolloutPtrs { float* obs; float* rew; uint8_t* done; uint8_t* trunc; float* tobs; float* ep_ret; int32_t* ep_len; };

@@ -180,6 +180,9 @@ static const double SO100_PAD_SIZE[SO100_NPAD][3] = {
  * Contact parameters: MuJoCo's defaults (the meshes' class sets none).  Parity: unpinned by construction. */
 #define SO100_NPROX 5
 static const int SO100_PROX_LINK[SO100_NPROX] = { 1, 2, 3, 4, 5 };
+/* SO100_F_LINKS_CUBE: the same rule on links 0 (Rotation_Pitch) and 1 (Upper_Arm) -- segment from the link's joint origin to its child's, radius from
+ * the inertia box -- against block_a: the two arm bodies that scene:44-48 does NOT exclude from colliding with the cube. */
+#define SO100_NCPROX 2
 #define SO100_PROX_JAW_RADIUS_MAX 0.008   /* a jaw is a thin finger (pads: 8 mm half height): its inertia box -- it carries the servo -- would give a 2 cm capsule that buries the pads */
 
 #endif /* SO100_MODEL_DEF_H */

@@ -139,7 +139,7 @@ __device__ __forceinline__ void physics_phase_mw(const SimParams& p, int wave, i
     // for the substep loop and steps it concurrently (cube/floor Newton ~ 900 instructions per substep in contact).
     const bool cube_live = (p.flags & F_CUBE_PINNED) == 0u;
     const bool pads = PADS && (p.flags & F_ANY_CONTACT) != 0u;
-    const bool padcube = PADS && (p.flags & F_PADS_CUBE) != 0u && cube_live;
+    const bool padcube = PADS && (p.flags & F_ARM_CUBE) != 0u && cube_live;       // pad/cube or link/cube pairs: the contact wave needs the cube's state
     Cube<float> cb; CubePrep<float> cprep;
     float applied[3] = { 0.0f, 0.0f, 0.0f };
     memo = ContactMemo{};                                      // every kernel starts an env step without active-set memory: one definition of the solve
@@ -575,7 +575,7 @@ __global__ void __launch_bounds__(64*NW) so100_rollout_fused(SimParams p, float*
     static_assert(!XW || MAXPADC*CF*64 + 36*64 <= MAXC*CF*64, "joint frames must fit in the unused tail of the contact store");
     float (*xw)[64] = XW ? reinterpret_cast<float (*)[64]>(pool + MAXPADC*CF*64) : nullptr;
     constexpr bool PADS = FL < 0 || (FL & (int)F_ANY_CONTACT) != 0;
-    constexpr bool LINKS = FL < 0 || (FL & (int)F_LINKS_FLOOR) != 0;
+    constexpr bool LINKS = FL < 0 || (FL & (int)F_ANY_LINKS) != 0;
     __shared__ float xa[PADS ? 15 : 1][64];                       // pad contacts: the contact wave's accelerations, contact code, residual, set signature
     __shared__ float xk[PADS ? 12 : 1][64];                       //               ctrl and arm warm start of the env step
     __shared__ float xn[6][64];                                   // next step's policy noise, pre-drawn by wave 3 during the physics phase

@@ -80,10 +80,10 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     if (cfg->contact_iters < 1 || cfg->contact_iters > 64) return fail(SO100_E_INVALID, "so100_create: contact_iters must be in 1..64%s");
     if (cfg->frame_skip < 1 || cfg->frame_skip > 1024) return fail(SO100_E_INVALID, "so100_create: frame_skip must be in 1..1024%s");
     if (cfg->max_episode_steps < 0) return fail(SO100_E_INVALID, "so100_create: max_episode_steps must be >= 0%s");
-    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR))
+    if (cfg->flags & ~(SO100_F_FRICTIONLOSS | SO100_F_LIMITS | SO100_F_FLOOR | SO100_F_CUBE_PINNED | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR | SO100_F_LINKS_CUBE))
         return fail(SO100_E_INVALID, "so100_create: unknown flag bits%s");
-    if ((cfg->flags & SO100_F_PADS_CUBE) && (cfg->flags & SO100_F_CUBE_PINNED))
-        return fail(SO100_E_INVALID, "so100_create: SO100_F_PADS_CUBE needs a dynamic cube (not SO100_F_CUBE_PINNED)%s");
+    if ((cfg->flags & (SO100_F_PADS_CUBE | SO100_F_LINKS_CUBE)) && (cfg->flags & SO100_F_CUBE_PINNED))
+        return fail(SO100_E_INVALID, "so100_create: SO100_F_PADS_CUBE / SO100_F_LINKS_CUBE need a dynamic cube (not SO100_F_CUBE_PINNED)%s");
     if (cfg->envs_per_workgroup != 0 && cfg->envs_per_workgroup != 16 && cfg->envs_per_workgroup != 32 && cfg->envs_per_workgroup != 64)
         return fail(SO100_E_INVALID, "so100_create: envs_per_workgroup must be 0 (automatic), 16, 32 or 64%s");
     if ((cfg->flags & SO100_F_FLOOR) && (cfg->flags & SO100_F_CUBE_PINNED))
@@ -110,7 +110,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
         int cus = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
         int epw = 64;
-        if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR))
+        if (cfg->flags & (SO100_F_FLOOR | SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR | SO100_F_LINKS_CUBE))
             while (epw > 16 && (cfg->num_envs + epw/2 - 1)/(epw/2) <= cus) epw /= 2;
         // contact disabled (no data-dependent solve): 32 envs per workgroup while that fits the CUs -- the persistent kernel's policy phase then
         // runs one 32-row MFMA tile per tower instead of two (so100_rollout_fused<K, 8, 4, 32>: half the matrix-core time per step)
@@ -130,7 +130,7 @@ int so100_create(const so100_config* cfg, so100_sim** out) {
     }
     {   // workgroup load balancing of the persistent rollout kernel (pad-contact variants, batches it serves; SO100_BALANCE=0 turns it off)
         const char* bal = getenv("SO100_BALANCE");
-        const bool pads = (cfg->flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR)) != 0;
+        const bool pads = (cfg->flags & (SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR | SO100_F_LINKS_CUBE)) != 0;
         if (pads && cfg->num_envs <= BALANCE_MAX_ENVS && !(bal && atoi(bal) == 0)) {
             const size_t slots = (size_t)((cfg->num_envs + s->prm.epw - 1)/s->prm.epw)*(size_t)s->prm.epw;
             if (hipMalloc(&s->slot_env, slots*sizeof(int32_t)) != hipSuccess) {

@@ -15,11 +15,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SO100_LIB", os.path.join(_HERE, "libso100sim.so"))   # SO100_LIB: A/B builds of the same ABI (tools/)
 
 ENV01, ENV02, ENV03, ENV04, ENV05, ENV06 = 1, 2, 3, 4, 5, 6
-F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE, F_LINKS_FLOOR = 1, 2, 4, 8, 16, 32, 64
+F_FRICTIONLOSS, F_LIMITS, F_FLOOR, F_CUBE_PINNED, F_PADS_FLOOR, F_PADS_CUBE, F_LINKS_FLOOR, F_LINKS_CUBE = 1, 2, 4, 8, 16, 32, 64, 128
 F_REFERENCE = F_FRICTIONLOSS | F_LIMITS | F_FLOOR | F_PADS_FLOOR     # what the reference scene simulates (minus its mesh geoms)
 F_NOPADS = F_FRICTIONLOSS | F_LIMITS | F_FLOOR                         # round-1 "reference": no arm contact at all
 F_CONTACT5 = F_REFERENCE | F_PADS_CUBE                                  # BASELINE.json configs[4]: finger pads vs cube, coupled solve
 F_REFERENCE_LINKS = F_REFERENCE | F_LINKS_FLOOR                         # + capsule proxies of the arm's collision meshes vs the floor (a documented stand-in)
+F_REFERENCE_PROXIES = F_REFERENCE_LINKS | F_LINKS_CUBE                  # + Rotation_Pitch / Upper_Arm capsules vs the cube (needs a dynamic cube)
 B_BAD_STATE = 128            # bit of the `bits` state row latched when a non-finite state ended an episode (csrc/so100_task.hpp)
 NINJECT = 16
 ABI_VERSION = 3              # include/so100_sim.h: SO100_ABI_VERSION
@@ -327,7 +328,7 @@ class So100Sim:
     def contacts_dropped(self):
         """int32 [N]: contacts dropped over the 16-record budget in the last env step (0 where the contact flags are off).  MuJoCo would keep
         them: an env that reports > 0 deviates from the reference model in that step (a jaw lying flat on the table)."""
-        if (self.cfg.flags & (F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR)) == 0:
+        if (self.cfg.flags & (F_PADS_FLOOR | F_PADS_CUBE | F_LINKS_FLOOR | F_LINKS_CUBE)) == 0:
             return torch.zeros(self.n, dtype=torch.int32, device=self.device)
         return self.get_field("contact_stat", dtype=torch.int32) >> 8
 

@@ -88,7 +88,17 @@ template <typename T> static int bb(const double* cA, const double* RA, const do
     for (int i = 0; i < 3; i++) nrm[i] = n[i];
     return cnt;
 }
+template <typename T> static int capbox(const double* a, const double* b, double r, const double* c, const double* R, const double* h, double* pos, double* nrm, double* dist) {
+    T a_[3], b_[3], c_[3], R_[9], h_[3], p[3], n[3], d = T(0);
+    for (int i = 0; i < 3; i++) { a_[i] = (T)a[i]; b_[i] = (T)b[i]; c_[i] = (T)c[i]; h_[i] = (T)h[i]; }
+    for (int i = 0; i < 9; i++) R_[i] = (T)R[i];
+    const int k = capsule_box<T>(a_, b_, (T)r, c_, R_, h_, p, n, d);
+    if (k) { for (int i = 0; i < 3; i++) { pos[i] = p[i]; nrm[i] = n[i]; } *dist = d; }
+    return k;
+}
 extern "C" {
+int hc_capbox_d(const double* a, const double* b, double r, const double* c, const double* R, const double* h, double* pos, double* nrm, double* dist) { return capbox<double>(a, b, r, c, R, h, pos, nrm, dist); }
+int hc_capbox_f(const double* a, const double* b, double r, const double* c, const double* R, const double* h, double* pos, double* nrm, double* dist) { return capbox<float>(a, b, r, c, R, h, pos, nrm, dist); }
 void hc_csub_d(double* st, const double* ctrl, const double* ap, unsigned fg, int it, int cit, int n, int* stat) { csub<double>(st, ctrl, ap, fg, it, cit, n, stat); }
 void hc_csub_f(double* st, const double* ctrl, const double* ap, unsigned fg, int it, int cit, int n, int* stat) { csub<float>(st, ctrl, ap, fg, it, cit, n, stat); }
 int hc_boxbox_d(const double* cA, const double* RA, const double* hA, const double* cB, const double* RB, const double* hB, double* pos, double* nrm, double* dist) { return bb<double>(cA, RA, hA, cB, RB, hB, pos, nrm, dist); }

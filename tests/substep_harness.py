@@ -34,7 +34,7 @@ def feature_mix(fid):
 def oracle_contact_summary(d):
     """(records the device keeps, signature of the pad-contact set, pad contacts, coupled) of the oracle's last forward pass"""
     pads = [d.con[i] for i in range(d.ncon) if d.con[i].kind != 0]
-    coupled = any(c.kind == 2 for c in pads)
+    coupled = any(c.kind in (2, 4) for c in pads)                # pad/cube or link proxy/cube: arm and cube solved together
     n = len(pads) + (sum(1 for i in range(d.ncon) if d.con[i].kind == 0) if coupled else 0)
     sig = sum(feature_mix(c.feat) for c in pads) & 0xFFFFFFFF
     return n, (sig - (1 << 32) if sig >= (1 << 31) else sig), len(pads), coupled

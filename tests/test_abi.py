@@ -81,3 +81,15 @@ def test_integration_doc_matches_abi():
     hdr = open(os.path.join(ROOT, "include", "so100_sim.h")).read()
     step_io = hdr.split("typedef struct {", 3)[2].split("} so100_step_io;")[0]
     assert re.findall(r"(\w+_dev);", step_io) == io_names
+
+
+def test_library_is_not_older_than_its_sources():
+    """`make -q`: the in-tree libso100sim.so (what travels to the GPU box) was built from the kernel sources as they are now.  A stale library
+    silently tests yesterday's kernels against today's oracle (it happened: a narrowphase changed in oracle + host check, the .so was not rebuilt)."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "so100_mujoco_rl_amd", "csrc")
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no build tools here")
+    assert subprocess.call(["make", "-q", "-C", csrc], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0, \
+        "so100_mujoco_rl_amd/libso100sim.so is older than csrc/*: run `make -C so100_mujoco_rl_amd/csrc -j7` (or __graft_entry__.build())"

@@ -76,3 +76,20 @@ def test_pad_cube_grasp_per_substep(n):
     qpos, qvel, act = SH.grasp_batch(m, 1)
     T = SH.run_substep_parity(HipDevice(n, m, C5), qpos, qvel, act, C5, nsub, f"HIP n={n} grasp")
     _check(T, m*nsub//3, m*nsub//4)
+
+
+@pytest.mark.parametrize("n", [32, 8192, 16384 + 32])
+def test_link_cube_per_substep(n):
+    """SO100_F_LINKS_CUBE (Rotation_Pitch / Upper_Arm capsules vs the cube: the pairs the reference scene leaves live) through the
+    run-time-flags kernels -- 4 / 2 / 1 contact lanes per env and the one-wave kernel: the cube placed against either capsule, arm and cube
+    solved together (12 unknowns, records on links 0 / 1); then the closing-jaw grasp with every proxy pair switched on as well"""
+    from test_substep_parity import link_cube_batch, LCUBE
+    m, nsub = 32, 12
+    qpos, qvel, act = link_cube_batch(m, 0)
+    T = SH.run_substep_parity(HipDevice(n, m, LCUBE), qpos, qvel, act, LCUBE, nsub, f"HIP n={n} link proxies vs cube")
+    _check(T, m*nsub//3, m*nsub//3)
+    if n == 32:
+        flags = LCUBE | O.F_PADS_CUBE
+        qpos, qvel, act = SH.grasp_batch(m, 2)
+        T = SH.run_substep_parity(HipDevice(n, m, flags), qpos, qvel, act, flags, 32, f"HIP n={n} all proxies + grasp")
+        _check(T, m*32//4, m*32//5)

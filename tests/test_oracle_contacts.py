@@ -403,3 +403,139 @@ def test_link_proxy_rows_satisfy_kkt_and_newton_equals_pgs():
                 assert f[r] >= -1e-12 and abs(f[r] - max(0.0, -jar[r]/Rr[r])) < 1e-6*(1 + abs(f[r]))
         Mq = O.arr(d.M).reshape(12, 12)
         assert np.allclose(Mq[:6, :6] @ (O.arr(d.qacc) - O.arr(d.qacc_smooth))[:6], (J.T @ f)[:6], atol=1e-8)
+
+
+# ---- link proxies against the cube (SO100_F_LINKS_CUBE: Rotation_Pitch / Upper_Arm, the pairs scene:44-48 leaves live) ---
+LCUBE = O.F_REFERENCE | O.F_LINKS_FLOOR | O.F_LINKS_CUBE
+
+
+def capsule_box(a, b, r, c, R, h):
+    p = lambda x: np.ascontiguousarray(x, np.float64).ctypes.data_as(C.c_void_p)
+    pos = np.zeros(3); n = np.zeros(3); dist = C.c_double(0)
+    L.so100o_capsule_box.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    k = L.so100o_capsule_box(p(a), p(b), float(r), p(c), p(R), p(h), p(pos), p(n), C.byref(dist))
+    return k, pos, n, dist.value
+
+
+def _segment_box_distance(a, b, c, R, h, samples=4001):
+    t = np.linspace(0, 1, samples)[:, None]
+    s = ((a + t*(b - a)) - c) @ R                            # box frame (R: world <- box, row-major)
+    e = s - np.clip(s, -h, h)
+    return np.sqrt((e*e).sum(1)).min()
+
+
+def test_capsule_box_known_configurations():
+    I = np.eye(3); h = np.full(3, 0.01); r = 0.02
+    # segment parallel to the top face, 1 mm of penetration: one contact, normal capsule -> box = straight down, midway between the surfaces
+    k, pos, n, dist = capsule_box([-0.05, 0.002, 0.029], [0.05, 0.002, 0.029], r, [0, 0, 0], I, h)
+    assert k == 1 and dist == pytest.approx(-0.001, abs=1e-12) and np.allclose(n, [0, 0, -1]) and pos[2] == pytest.approx(0.0095, abs=1e-12)
+    assert abs(pos[0]) <= 0.01 + 1e-12 and pos[1] == pytest.approx(0.002)
+    # end-on: the segment points at the +x face from outside
+    k, pos, n, dist = capsule_box([0.0295, 0, 0], [0.2, 0, 0], r, [0, 0, 0], I, h)
+    assert k == 1 and dist == pytest.approx(-0.0005, abs=1e-12) and np.allclose(n, [-1, 0, 0])
+    # separated
+    assert capsule_box([0.031, 0, 0], [0.2, 0, 0], r, [0, 0, 0], I, h)[0] == 0
+    # the axis passes through the box: leaves through the nearest face (here +z), depth = face distance + radius
+    k, pos, n, dist = capsule_box([-0.05, 0, 0.006], [0.05, 0, 0.006], r, [0, 0, 0], I, h)
+    assert k == 1 and np.allclose(n, [0, 0, -1]) and dist == pytest.approx(-(0.004 + r), abs=1e-12)
+
+
+def test_capsule_box_fuzz_invariants():
+    """unit normal; rigid-motion equivariance; the distance equals the true (densely sampled) segment-box distance minus the radius"""
+    rs = np.random.RandomState(4); hits = 0; worst = 0.0
+    for _ in range(3000):
+        R, _ = rot(rs); c = rs.randn(3)*0.1; h = np.full(3, 0.01); r = 0.02 + 0.004*rs.rand()
+        u = rs.randn(3); u /= np.linalg.norm(u)
+        mid = c + u*(0.01 + r)*(0.6 + 0.9*rs.rand()); w = rs.randn(3); w /= np.linalg.norm(w)
+        ln = 0.1 + 0.02*rs.rand(); t0 = rs.rand()
+        a = mid - w*ln*t0; b = mid + w*ln*(1 - t0)
+        k, pos, n, dist = capsule_box(a, b, r, c, R, h)
+        true = _segment_box_distance(a, b, c, R, h) - r
+        if k == 0:
+            assert true > -2e-4
+            continue
+        hits += 1
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and dist <= 0
+        if true > -r + 1e-4:                                  # (axis outside the box)
+            assert dist >= true - 1e-6                        # (the sampled minimum is itself only good to ~1e-7)
+            worst = max(worst, dist - true)
+        Q, _ = rot(rs); t = rs.randn(3)
+        k2, pos2, n2, dist2 = capsule_box(Q @ a + t, Q @ b + t, r, Q @ c + t, Q @ R, h)
+        assert k2 == 1 and np.allclose(pos2, Q @ pos + t, atol=1e-10) and np.allclose(n2, Q @ n, atol=1e-10) and dist2 == pytest.approx(dist, abs=1e-10)
+    assert hits > 1000
+    assert worst < 1e-6, worst                                # the bracketed Newton lands on the minimiser (the sampled reference is good to ~1e-7)
+
+
+def test_cube_proxy_geometry_follows_its_rule():
+    d = fresh(np.array([0.3, -1.2, 1.0, 0.4, 0.2, 0.5])); L.so100o_kinematics(C.byref(M), C.byref(d))
+    xp = O.arr(d.xpos); xm = O.arr(d.xmat)
+    for k in range(O.NCPROX):
+        b = M.cprox_body[k]; assert b == k + 2               # Rotation_Pitch, Upper_Arm
+        assert np.allclose(np.array(M.cprox_p[k][0][:]), 0)
+        assert np.allclose(xp[b] + xm[b].reshape(3, 3) @ np.array(M.cprox_p[k][1][:]), xp[b + 1], atol=1e-12)
+        assert 0.015 < M.cprox_radius[k] < 0.03
+    assert M.cprox_radius[1] == M.prox_radius[0]             # the Upper_Arm capsule is the one the floor pairs use
+
+
+def link_cube_states(n, seed, pen=(0.0002, 0.003)):
+    """arm poses with the cube placed against the Rotation_Pitch (even i) or Upper_Arm (odd i) capsule, penetrating by pen[0]..pen[1] metres"""
+    rs = np.random.RandomState(seed); out = []
+    hs = np.full(3, 0.01)
+    while len(out) < n:
+        k = len(out) % 2
+        q = LO + (HI - LO)*rs.rand(6)
+        d = fresh(q); L.so100o_kinematics(C.byref(M), C.byref(d))
+        xp = O.arr(d.xpos); b = M.cprox_body[k]
+        a_, b_ = xp[b].copy(), xp[b + 1].copy()
+        s = a_ + (0.15 + 0.85*rs.rand())*(b_ - a_)
+        u = rs.randn(3); u /= np.linalg.norm(u)
+        Rc, qc = rot(rs)
+        want = -(pen[0] + (pen[1] - pen[0])*rs.rand())
+        lo_, hi_ = 0.0, 0.08                                 # bisection on the cube's offset along u for the wanted penetration
+        for _ in range(40):
+            mid = 0.5*(lo_ + hi_)
+            kk, _, _, dist = capsule_box(a_, b_, M.cprox_radius[k], s + u*mid, Rc, hs)
+            if kk and dist < want: lo_ = mid
+            else: hi_ = mid
+        c = s + u*lo_
+        kk, _, _, dist = capsule_box(a_, b_, M.cprox_radius[k], c, Rc, hs)
+        if not kk or abs(dist - want) > 2e-4 or c[2] < 0.012 + 0.0174:      # (cube clear of the floor: the pair under test alone)
+            continue
+        # no other proxy / pad may touch anything in this pose
+        dd = fresh(q); O.arr(dd.qpos)[6:9] = c; O.arr(dd.qpos)[9:13] = qc
+        fwd(dd, LCUBE | O.F_PADS_CUBE, -1)
+        if dd.ncon != 1 or dd.con[0].kind != 4:
+            continue
+        out.append((q, c, qc))
+    return out
+
+
+def test_link_cube_contact_pushes_the_cube_away_and_satisfies_kkt():
+    """with SO100_F_LINKS_CUBE a cube that overlaps the Upper_Arm / Rotation_Pitch capsule is pushed out along the contact normal and the
+    rows satisfy the KKT conditions; without the flag (F_REFERENCE_LINKS) the same cube falls freely through the link"""
+    for q, c, qc in link_cube_states(6, 2):
+        d = fresh(q); O.arr(d.qpos)[6:9] = c; O.arr(d.qpos)[9:13] = qc
+        fwd(d, LCUBE, -1)
+        assert d.ncon == 1 and d.con[0].kind == 4 and d.con[0].feat in (160, 161) and d.con[0].b2 == 8
+        nrm = np.array(d.con[0].frame[:3])
+        n = d.nefc
+        J = O.arr(d.efc_J)[:n]; f = O.arr(d.efc_force)[:n]; aref = O.arr(d.efc_aref)[:n]; Rr = O.arr(d.efc_R)[:n]; ty = np.ctypeslib.as_array(d.efc_type)[:n]
+        jar = J @ O.arr(d.qacc) - aref
+        for r in range(n):
+            if ty[r] != 0:
+                assert f[r] >= -1e-12 and abs(f[r] - max(0.0, -jar[r]/Rr[r])) < 1e-6*(1 + abs(f[r]))
+        Mq = O.arr(d.M).reshape(12, 12)
+        assert np.allclose(Mq @ (O.arr(d.qacc) - O.arr(d.qacc_smooth)), J.T @ f, atol=1e-7)
+        assert f[ty == 2].sum() > 0                           # the pair carries force
+        acc_cube = O.arr(d.qacc)[6:9] - np.array([0, 0, -9.81])
+        assert acc_cube @ nrm > 1.0                           # ... that pushes the cube along the normal (capsule -> cube)
+        # without the flag: free fall
+        d2 = fresh(q); O.arr(d2.qpos)[6:9] = c; O.arr(d2.qpos)[9:13] = qc
+        fwd(d2, LINKS, -1)
+        assert d2.ncon == 0 and np.allclose(O.arr(d2.qacc)[6:9], [0, 0, -9.81], atol=1e-9)
+        # 20 substeps on: the penetration has not grown, nothing blew up
+        O.arr(d.ctrl)[:] = q
+        L.so100o_step(C.byref(M), C.byref(d), LCUBE, -1, 20)
+        assert np.all(np.isfinite(O.arr(d.qpos))) and np.abs(O.arr(d.qvel)[:9]).max() < 2.0      # (the 8 g cube may spin: an off-centre push with friction)
+        L.so100o_forward(C.byref(M), C.byref(d), LCUBE, -1)
+        assert d.ncon == 0 or d.con[0].dist > -0.004

@@ -115,3 +115,30 @@ def test_link_proxies_with_the_coupled_grasp_per_substep_host_fp32(H):
     qpos, qvel, act = SH.grasp_batch(n, 1)
     T = SH.run_substep_parity(HostDevice(H, n, flags), qpos, qvel, act, flags, 40, "host fp32, link proxies + grasp")
     _check(T, n_pairs_min_contact=n*40//4, coupled_min=n*40//5)
+
+
+# ---- link proxies against the cube (SO100_F_LINKS_CUBE: Rotation_Pitch / Upper_Arm vs block_a) ---------------------------
+LCUBE = O.F_REFERENCE | O.F_LINKS_FLOOR | O.F_LINKS_CUBE
+
+
+def link_cube_batch(n, seed):
+    """the cube placed against the Rotation_Pitch / Upper_Arm capsule (alternating), 0.2-3 mm deep, random joint and cube velocities"""
+    from test_oracle_contacts import link_cube_states
+    rs = np.random.RandomState(seed)
+    qpos = np.zeros((n, 13)); qvel = np.zeros((n, 12))
+    for i, (q, c, qc) in enumerate(link_cube_states(n, seed + 3)):
+        qpos[i, :6] = q; qpos[i, 6:9] = c; qpos[i, 9:13] = qc
+        qvel[i, :6] = rs.randn(6)*0.3; qvel[i, 6:9] = rs.randn(3)*0.02
+    act = rs.uniform(-1, 1, (n, 6)).astype(np.float32)
+    return qpos, qvel, act
+
+
+def test_link_cube_per_substep_host_fp32(H):
+    n = 32
+    qpos, qvel, act = link_cube_batch(n, 0)
+    T = SH.run_substep_parity(HostDevice(H, n, LCUBE), qpos, qvel, act, LCUBE, 12, "host fp32, link proxies vs cube")
+    _check(T, n_pairs_min_contact=n*12//3, coupled_min=n*12//3)
+    flags = LCUBE | O.F_PADS_CUBE                            # the closing-jaw grasp with every proxy pair switched on as well
+    qpos, qvel, act = SH.grasp_batch(16, 2)
+    T = SH.run_substep_parity(HostDevice(H, 16, flags), qpos, qvel, act, flags, 32, "host fp32, all proxies + grasp")
+    _check(T, n_pairs_min_contact=16*32//4, coupled_min=16*32//5)
