@@ -101,7 +101,19 @@ static void cholesky(const double* A, double* L, int n);
 static void chol_solve(const double* L, int n, const double* b, double* x);
 void so100o__crb(const so100o_model* m, so100o_data* d);
 
-void so100o_model_init(so100o_model* m) {
+void so100o_model_init(so100o_model* m) { so100o_model_init_with_inertials(m, NULL); }
+
+/* inert: NULL = the MJCF's <inertial> elements (arm:73-74 ... 113-114), else 6 rows "mass ipos(3) iquat(4) diaginertia(3)" for Rotation_Pitch ...
+ * Moving_Jaw -- the escape hatch for SURVEY.md A.1's assumption that the scene's inertiafromgeom="true" does not reach the attached arm model
+ * (csrc/gen_model.cpp takes the same table: make gen INERTIALS=file).  Everything derived from them (M0, invweights, kv, proxy radii) follows. */
+void so100o_model_init_with_inertials(so100o_model* m, const double* inert) {
+    double LMASS[SO100_NLINK], LIPOS[SO100_NLINK][3], LIQUAT[SO100_NLINK][4], LDIAG[SO100_NLINK][3];
+    for (int k = 0; k < SO100_NLINK; k++) {
+        const double* r = inert ? inert + 11*k : NULL;
+        LMASS[k] = r ? r[0] : SO100_LINK_MASS[k];
+        for (int a = 0; a < 3; a++) { LIPOS[k][a] = r ? r[1 + a] : SO100_LINK_IPOS[k][a]; LDIAG[k][a] = r ? r[8 + a] : SO100_LINK_DIAGINERTIA[k][a]; }
+        for (int a = 0; a < 4; a++) LIQUAT[k][a] = r ? r[4 + a] : SO100_LINK_IQUAT[k][a];
+    }
     memset(m, 0, sizeof *m);
     /* bodies 0 world, 1 Base: identity frames, no joints */
     for (int b = 0; b < NB; b++) {
@@ -120,11 +132,11 @@ void so100o_model_init(so100o_model* m) {
         } else {
             euler2quat(m->body_quat[b], SO100_LINK_ORI[k]);
         }
-        memcpy(m->body_ipos[b], SO100_LINK_IPOS[k], sizeof(double)*3);
-        memcpy(m->body_iquat[b], SO100_LINK_IQUAT[k], sizeof(double)*4);
+        memcpy(m->body_ipos[b], LIPOS[k], sizeof(double)*3);
+        memcpy(m->body_iquat[b], LIQUAT[k], sizeof(double)*4);
         quat_normalize(m->body_iquat[b]);
-        m->body_mass[b] = SO100_LINK_MASS[k];
-        memcpy(m->body_inertia[b], SO100_LINK_DIAGINERTIA[k], sizeof(double)*3);
+        m->body_mass[b] = LMASS[k];
+        memcpy(m->body_inertia[b], LDIAG[k], sizeof(double)*3);
         memcpy(m->jnt_axis[b], SO100_JNT_AXIS[k], sizeof(double)*3);
         m->jnt_range[k][0] = SO100_JNT_RANGE[k][0]; m->jnt_range[k][1] = SO100_JNT_RANGE[k][1];
         m->armature[k] = SO100_JNT_ARMATURE; m->frictionloss[k] = SO100_JNT_FRICTIONLOSS;
@@ -172,7 +184,7 @@ void so100o_model_init(so100o_model* m) {
             }
             m->prox_p[k][1][0] = 0.5*(xlo + xhi); m->prox_p[k][1][1] = ymax; m->prox_p[k][1][2] = 0.0;
         }
-        const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+        const double* I = LDIAG[l]; const double mass = LMASS[l];
         double h[3] = { 0.5*sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
         const double hmax = fmax(h[0], fmax(h[1], h[2]));
         double r = 0.5*(h[0] + h[1] + h[2] - hmax);
@@ -185,7 +197,7 @@ void so100o_model_init(so100o_model* m) {
         m->cprox_body[k] = l + 2;
         memset(m->cprox_p[k], 0, sizeof m->cprox_p[k]);
         memcpy(m->cprox_p[k][1], SO100_LINK_POS[l + 1], sizeof(double)*3);
-        const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+        const double* I = LDIAG[l]; const double mass = LMASS[l];
         double h[3] = { 0.5*sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
         const double hmax = fmax(h[0], fmax(h[1], h[2]));
         m->cprox_radius[k] = 0.5*(h[0] + h[1] + h[2] - hmax);

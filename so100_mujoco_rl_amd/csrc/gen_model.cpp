@@ -11,6 +11,10 @@
 //     actuator kv = dampratio * 2 sqrt(kp * dof_M0), default-solref K and B, friction-row R,
 //   * cube mass / inertia from the box geom.
 // Output: so100_model_gen.h (constexpr tables).  Build + run:  make -C so100_mujoco_rl_amd/csrc gen
+// Escape hatch for SURVEY.md A.1's inertia assumption (the arm keeps its explicit <inertial> elements under the scene's inertiafromgeom="true";
+// if MuJoCo's compiler instead derives them from the mesh geoms, the numbers are only known to who can run MuJoCo):
+//   make gen INERTIALS=file      file = 6 lines "mass  ipos(3)  iquat(4, wxyz)  diaginertia(3)" = MjModel.body_mass / body_ipos / body_iquat /
+//   body_inertia of the bodies Rotation_Pitch ... Moving_Jaw; '#' starts a comment.  The oracle takes the same table (so100o_model_init_with_inertials).
 // The result is cross-checked against the oracle's independent derivation in tests/test_model_def.py.
 #include <cmath>
 #include <cstdio>
@@ -57,6 +61,27 @@ static void emit1(FILE* f, const char* name, const double* v, int n) {
 
 int main(int argc, char** argv) {
     const int N = SO100_NLINK;
+    // the arm links' inertials: the MJCF's <inertial> elements, or the override table (see the header comment)
+    double LMASS[SO100_NLINK], LIPOS[SO100_NLINK][3], LIQUAT[SO100_NLINK][4], LDIAG[SO100_NLINK][3];
+    for (int k = 0; k < N; k++) {
+        LMASS[k] = SO100_LINK_MASS[k];
+        std::memcpy(LIPOS[k], SO100_LINK_IPOS[k], sizeof LIPOS[k]); std::memcpy(LIQUAT[k], SO100_LINK_IQUAT[k], sizeof LIQUAT[k]); std::memcpy(LDIAG[k], SO100_LINK_DIAGINERTIA[k], sizeof LDIAG[k]);
+    }
+    const char* inert_file = argc > 2 && argv[2][0] ? argv[2] : nullptr;
+    if (inert_file) {
+        FILE* fi = std::fopen(inert_file, "r");
+        if (!fi) { std::perror(inert_file); return 1; }
+        char line[512]; int k = 0;
+        while (k < N && std::fgets(line, sizeof line, fi)) {
+            if (char* h = std::strchr(line, '#')) *h = 0;
+            double v[11];
+            if (std::sscanf(line, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", v, v+1, v+2, v+3, v+4, v+5, v+6, v+7, v+8, v+9, v+10) != 11) continue;
+            LMASS[k] = v[0]; for (int a = 0; a < 3; a++) { LIPOS[k][a] = v[1+a]; LDIAG[k][a] = v[8+a]; } for (int a = 0; a < 4; a++) LIQUAT[k][a] = v[4+a];
+            k++;
+        }
+        std::fclose(fi);
+        if (k != N) { std::fprintf(stderr, "%s: %d of %d inertial lines (11 numbers each)\n", inert_file, k, N); return 1; }
+    }
     double C[N][9], P[N][3], COM[N][3], H[N][3], ICOM[N][6], IORG[N][6], MASS[N];
     int AX[N];
     for (int k = 0; k < N; k++) {
@@ -66,12 +91,12 @@ int main(int argc, char** argv) {
         q2m(C[k], q);
         std::memcpy(P[k], SO100_LINK_POS[k], sizeof P[k]);
         AX[k] = SO100_JNT_AXIS[k][0] == 1 ? 0 : (SO100_JNT_AXIS[k][1] == 1 ? 1 : 2);
-        MASS[k] = SO100_LINK_MASS[k];
-        std::memcpy(COM[k], SO100_LINK_IPOS[k], sizeof COM[k]);
-        double iq[4]; std::memcpy(iq, SO100_LINK_IQUAT[k], sizeof iq); qnorm(iq);
+        MASS[k] = LMASS[k];
+        std::memcpy(COM[k], LIPOS[k], sizeof COM[k]);
+        double iq[4]; std::memcpy(iq, LIQUAT[k], sizeof iq); qnorm(iq);
         double R[9], I[9];
         q2m(R, iq);
-        for (int i=0;i<3;i++) for (int j=0;j<3;j++) { double s=0; for (int a=0;a<3;a++) s+=R[3*i+a]*SO100_LINK_DIAGINERTIA[k][a]*R[3*j+a]; I[3*i+j]=s; }
+        for (int i=0;i<3;i++) for (int j=0;j<3;j++) { double s=0; for (int a=0;a<3;a++) s+=R[3*i+a]*LDIAG[k][a]*R[3*j+a]; I[3*i+j]=s; }
         double c[3] = {COM[k][0],COM[k][1],COM[k][2]}, cc = c[0]*c[0]+c[1]*c[1]+c[2]*c[2], IO[9];
         for (int i=0;i<3;i++) for (int j=0;j<3;j++) IO[3*i+j] = I[3*i+j] + MASS[k]*((i==j?cc:0.0) - c[i]*c[j]);
         const int ix[6][2] = {{0,0},{1,1},{2,2},{0,1},{0,2},{1,2}};
@@ -159,6 +184,7 @@ int main(int argc, char** argv) {
     std::fprintf(f, "// GENERATED by so100_mujoco_rl_amd/csrc/gen_model.cpp from so100_model_def.h -- do not edit.\n"
                     "// Link-frame model constants of the so100 arm scene (see gen_model.cpp for definitions).\n"
                     "#pragma once\nnamespace so100g {\n");
+    std::fprintf(f, "static constexpr bool INERTIALS_OVERRIDDEN = %s;      // true: built with `make gen INERTIALS=...` (MuJoCo's compiled body inertials instead of the MJCF's <inertial> elements)\n", inert_file ? "true" : "false");
     emit(f, "LINK_C", &C[0][0], N, 9);
     emit(f, "LINK_P", &P[0][0], N, 3);
     std::fprintf(f, "static constexpr int LINK_AXIS[%d] = { %d, %d, %d, %d, %d, %d };\n", N, AX[0],AX[1],AX[2],AX[3],AX[4],AX[5]);
@@ -204,7 +230,7 @@ int main(int argc, char** argv) {
                 }
                 far_[k][0] = 0.5*(xlo + xhi); far_[k][1] = ymax; far_[k][2] = 0.0;
             }
-            const double* I = SO100_LINK_DIAGINERTIA[l]; const double mass = SO100_LINK_MASS[l];
+            const double* I = LDIAG[l]; const double mass = LMASS[l];
             const double h[3] = { 0.5*std::sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*std::sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*std::sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
             const double hmax = std::fmax(h[0], std::fmax(h[1], h[2]));
             rad[k] = 0.5*(h[0] + h[1] + h[2] - hmax);
@@ -219,7 +245,7 @@ int main(int argc, char** argv) {
         double cfar[SO100_NCPROX][3], crad[SO100_NCPROX];
         for (int k = 0; k < SO100_NCPROX; k++) {
             for (int a = 0; a < 3; a++) cfar[k][a] = SO100_LINK_POS[k + 1][a];
-            const double* I = SO100_LINK_DIAGINERTIA[k]; const double mass = SO100_LINK_MASS[k];
+            const double* I = LDIAG[k]; const double mass = LMASS[k];
             const double h[3] = { 0.5*std::sqrt(6.0*(I[1] + I[2] - I[0])/mass), 0.5*std::sqrt(6.0*(I[0] + I[2] - I[1])/mass), 0.5*std::sqrt(6.0*(I[0] + I[1] - I[2])/mass) };
             crad[k] = 0.5*(h[0] + h[1] + h[2] - std::fmax(h[0], std::fmax(h[1], h[2])));
         }

@@ -12,7 +12,11 @@
 // Templated on the scalar T: float on the device; float/double host instantiations exist ONLY for the
 // CPU-side unit tests in tests/_hostcheck (never linked into libso100sim.so).
 #pragma once
+#if defined(SO100_MODEL_GEN_HEADER)      // a second generated model (tests of `make gen INERTIALS=...`)
+#include SO100_MODEL_GEN_HEADER
+#else
 #include "so100_model_gen.h"
+#endif
 
 #ifndef SO100_HD
 #if defined(__HIPCC__)
