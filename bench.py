@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 BYTES_PER_ENV_STEP = 452.0        # SURVEY.md section 8(d), Env01, fp32 SoA, 16 substeps fused
 # SURVEY.md section 8(d) per env kind: Env02 500 B, Env05 536 B, contact configs ~600 B (key: (kind, pad contacts on))
 BYTES_PER_ENV_STEP_BY_KIND = {(1, False): 452.0, (2, False): 500.0, (5, False): 536.0, (1, True): 600.0, (2, True): 648.0, (5, True): 684.0}
-CONTACT_BITS = 16 | 32 | 64       # SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR (include/so100_sim.h)
+CONTACT_BITS = 16 | 32 | 64 | 128 # SO100_F_PADS_FLOOR | SO100_F_PADS_CUBE | SO100_F_LINKS_FLOOR | SO100_F_LINKS_CUBE (include/so100_sim.h)
 FLOP_PER_ENV_STEP_SURVEY = 6.0e4  # SURVEY.md section 8(d) estimate, constraint-free
 # measured: PMC SQ_INSTS_VALU = 22.95 k VALU instructions per env-step lane (profiles/r01_c), of which ~45 % are FMAs
 # (ISA count: 1017 fma/fmac of 2100 float ops per substep) => ~1.45 FLOP per instruction => 3.3e4 FLOP per env-step.
@@ -56,6 +56,7 @@ WORKLOADS = {
     "env02_reference": (2, ("F_REFERENCE",), "reference physics (BASELINE.json configs[2] at this batch size)"),
     "env05_reference": (5, ("F_REFERENCE",), "reference physics (BASELINE.json configs[3] per-GPU shape)"),
     "env01_reference_links": (1, ("F_REFERENCE_LINKS",), "reference physics + capsule proxies of the arm links' collision meshes vs the floor (a documented stand-in; run-time-flags kernels)"),
+    "env01_reference_proxies": (1, ("F_REFERENCE_PROXIES",), "reference physics + every capsule proxy pair: links vs the floor, Rotation_Pitch / Upper_Arm vs the cube (SURVEY.md Q7; stand-ins; run-time-flags kernels)"),
     "env01_contact": (1, ("F_CONTACT5",), "reference physics + finger-pad/cube box-box contact, coupled arm+cube solve (BASELINE.json configs[4] per-GPU shape)"),
 }
 

@@ -4,7 +4,7 @@
 #   tools/final_round.sh <tag> b      rocprofv3 passes of env01_nopads / env01_contact + phase profiles (needs `python tools/rollout_prof.py build` here first)
 # then HERE: tools/copy_profiles.sh <tag> free nopads reference contact
 set -e
-TAG=${1:-r03_final}; PART=${2:-a}
+TAG=${1:-r03b_final}; PART=${2:-a}
 mkdir -p gpurun_out/$TAG
 if [ "$PART" = a ]; then
   tools/bench_all.sh $TAG > gpurun_out/$TAG/bench_all.txt 2>&1
