@@ -215,3 +215,76 @@ def test_link_proxies_keep_the_arm_above_the_table_on_the_gpu():
             L.so100o_step(C.byref(M), C.byref(d), F_REFERENCE_LINKS, -1, 16)
         worst = max(worst, np.abs(q[i, :6] - O.arr(d.qpos)[:6]).max())
     assert worst < 2e-2                                       # through the impact (a make / break a substep apart), see tests/test_gpu_contacts.py
+
+
+def test_link_cube_proxies_push_the_cube_and_survive_whole_rollouts_on_the_gpu():
+    """SO100_F_LINKS_CUBE (Rotation_Pitch / Upper_Arm capsules vs the cube) over whole env steps on the GPU.
+    (a) 64 cubes placed against a capsule (0.2 - 3 mm deep), arm servoed to hold its pose: after 8 env steps with the flag every cube has been pushed out along
+        the contact normal (no overlap deeper than 0.5 mm left) and nothing is non-finite; without it the same cubes fall freely through the link -- and 16 sampled
+        envs follow the oracle's env steps.
+    (b) every proxy pair on (SO100_F_REFERENCE_PROXIES) under a wild random policy, 1024 envs x 128 steps of Env01 and of Env03 (whose cube is moved around the
+        arm's workspace): finite states, contact budget never exceeded.  (No bound on the solver_residual row here: for contact-free substeps it holds the
+        acceleration change of the LAST block-PGS sweep, which under a wild policy exceeds 1e-2 rad/s^2 in ~10 % of the envs although the state after the step is
+        within 1e-6 rad / 1e-4 rad/s of the converged solve -- tools/pgs_probe.py)"""
+    import ctypes as C
+    from so100_mujoco_rl_amd.lib import So100Sim, F_REFERENCE_LINKS, F_REFERENCE_PROXIES
+    from test_oracle_contacts import link_cube_states, capsule_box, fresh, L, M
+    n = 64
+    states = link_cube_states(n, 21)
+    QP = np.zeros((n, 13))
+    for i, (q, c, qc) in enumerate(states):
+        QP[i, :6] = q; QP[i, 6:9] = c; QP[i, 9:13] = qc
+    act = np.zeros((n, 6), np.float32)
+
+    def overlap(qp):
+        """deepest capsule / cube penetration per env (0 when apart), from the oracle's kinematics"""
+        out = np.zeros(len(qp))
+        for i in range(len(qp)):
+            d = fresh(qp[i, :6]); O.arr(d.qpos)[6:13] = qp[i, 6:13]; L.so100o_kinematics(C.byref(M), C.byref(d))
+            xp = O.arr(d.xpos); xm = O.arr(d.xmat)
+            for k in range(O.NCPROX):
+                b = M.cprox_body[k]
+                kk, _, _, dist = capsule_box(xp[b], xp[b + 1], M.cprox_radius[k], xp[8], xm[8].reshape(3, 3), np.full(3, 0.01))
+                if kk: out[i] = min(out[i], dist)
+        return out
+
+    def run(flags, steps=8):
+        sim = So100Sim(1, n, flags=flags, seed=4, max_episode_steps=0)
+        sim.reset()
+        sim.set_state(torch.from_numpy(np.ascontiguousarray(QP.T, np.float32)).cuda(), torch.zeros(12, n, device="cuda"))
+        a = torch.from_numpy(act).cuda()
+        for _ in range(steps):
+            sim.step(a)
+        q, v = sim.get_state()
+        return q.cpu().numpy().T.astype(np.float64), v.cpu().numpy().T.astype(np.float64), sim.get_field("solver_residual").cpu().numpy()
+    assert overlap(QP).max() < -1e-4                         # every start state overlaps
+    q, v, res = run(F_REFERENCE_PROXIES)
+    ov = overlap(q)
+    print(f"[link/cube proxies, GPU] deepest overlap left after 8 env steps {ov.min()*1e3:.3f} mm (start {overlap(QP).min()*1e3:.2f} mm); worst residual {res.max():.1e}")
+    assert np.isfinite(q).all() and np.isfinite(v).all() and ov.min() > -5e-4 and res.max() < 1e-2
+    q0, v0, _ = run(F_REFERENCE_LINKS)
+    fell = QP[:, 8] - q0[:, 8]
+    free = 0.5*9.81*(8*16*0.002)**2                           # free fall over 8 env steps (cubes that reach the table stop there)
+    assert np.median(np.minimum(fell, free)) > 0.6*min(free, np.median(QP[:, 8]) - 0.01)
+    worst = 0.0
+    for i in range(0, n, 4):                                  # the oracle's env steps from the same states
+        d = fresh(); O.arr(d.qpos)[:] = QP[i].astype(np.float32)
+        for t in range(8):
+            O.arr(d.ctrl)[:] = O.arr(d.qpos)[:6].astype(np.float32).astype(np.float64)
+            L.so100o_step(C.byref(M), C.byref(d), F_REFERENCE_PROXIES, -1, 16)
+        worst = max(worst, np.abs(q[i, :9] - O.arr(d.qpos)[:9]).max())
+    print(f"[link/cube proxies, GPU] 16 envs x 8 env steps vs the oracle: worst |dq| {worst:.2e}")
+    assert worst < 5e-3                                       # (through the push-out: a make / break a substep apart, see tests/test_gpu_contacts.py)
+    # (b) soak with every proxy pair on
+    for kind in (1, 3):
+        sim = So100Sim(kind, 1024, flags=F_REFERENCE_PROXIES, seed=11)
+        sim.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(5)
+        dropped = 0
+        for t in range(128):
+            sim.step((torch.rand(1024, 6, device="cuda", generator=g)*2 - 1).contiguous())
+            if t % 16 == 15:
+                dropped = max(dropped, int(sim.contacts_dropped().max().item()))
+        q, v = sim.get_state()
+        assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(sim.obs).all()
+        assert dropped == 0, (kind, dropped)
