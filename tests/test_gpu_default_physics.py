@@ -38,7 +38,10 @@ def _start(env, col, qpos, qvel, kind):
     col._started = True
 
 
-@pytest.mark.parametrize("kind,flags", [(1, REFP), (2, C5), (5, REFP), (6, REFP), (3, REFP)])
+PROXIES = O.F_LINKS_FLOOR | O.F_LINKS_CUBE                 # every capsule proxy pair: the run-time-flags kernels so100_rollout_fused / so100_step_mw<K, -1>
+
+
+@pytest.mark.parametrize("kind,flags", [(1, REFP), (2, C5), (5, REFP), (6, REFP), (3, REFP), (1, REFP | PROXIES), (2, C5 | PROXIES)])
 def test_default_rollout_kernel_vs_stepwise_and_oracle(kind, flags):
     from so100_mujoco_rl_amd.vec_env import So100VecEnv
     from so100_mujoco_rl_amd.collector import RolloutCollector
