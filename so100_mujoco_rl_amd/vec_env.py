@@ -69,13 +69,15 @@ class So100VecEnv(_VecEnvBase):
     metadata = {"render_modes": [], "render_fps": K.RENDER_FPS}
 
     def __init__(self, env_id="Env01-v1", num_envs=4096, device=None, flags=F_REFERENCE, seed=0, env_id_offset=0,
-                 solver_iters=2, contact_iters=20, max_episode_steps=None, stagger_episodes=False, full_infos=False, use_graph=True):
+                 solver_iters=2, contact_iters=20, max_episode_steps=None, stagger_episodes=False, full_infos=False, use_graph=True,
+                 envs_per_workgroup=0):
         self.env_id = env_id
         self.kind = kind_from_id(env_id) if isinstance(env_id, str) else int(env_id)
         obs_space, act_space = make_spaces(self.kind)
         _VecEnvBase.__init__(self, num_envs, obs_space, act_space)
         self.sim = So100Sim(self.kind, num_envs, device=device, flags=flags, solver_iters=solver_iters, contact_iters=contact_iters,
-                            max_episode_steps=max_episode_steps, seed=seed, env_id_offset=env_id_offset)
+                            max_episode_steps=max_episode_steps, seed=seed, env_id_offset=env_id_offset,
+                            envs_per_workgroup=envs_per_workgroup)      # 0 = automatic; pin it when shards of another batch size must agree bit for bit
         self.device = self.sim.device
         self.full_infos = full_infos
         self._stagger = stagger_episodes
