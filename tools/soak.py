@@ -1,16 +1,17 @@
 """Long soak of the default rollout path: reference physics, staggered episodes, random policy; checks every chunk for
-non-finite values, the non-finite guard's latch, counters and device memory growth.   [PHYS=ref|c5|nopads|links|links_c5] python tools/soak.py [seconds] [envs] [env_id]"""
+non-finite values, the non-finite guard's latch, counters and device memory growth.   [PHYS=ref|c5|nopads|links|links_c5|proxies|proxies_c5] python tools/soak.py [seconds] [envs] [env_id]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from so100_mujoco_rl_amd.vec_env import So100VecEnv
 from so100_mujoco_rl_amd.collector import RolloutCollector
-from so100_mujoco_rl_amd.lib import F_REFERENCE, F_CONTACT5, F_NOPADS, F_REFERENCE_LINKS, F_PADS_CUBE
+from so100_mujoco_rl_amd.lib import F_REFERENCE, F_CONTACT5, F_NOPADS, F_REFERENCE_LINKS, F_REFERENCE_PROXIES, F_PADS_CUBE
 
 secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 env_id = sys.argv[3] if len(sys.argv) > 3 else "Env05-v1"
-flags = {"ref": F_REFERENCE, "c5": F_CONTACT5, "nopads": F_NOPADS, "links": F_REFERENCE_LINKS, "links_c5": F_REFERENCE_LINKS | F_PADS_CUBE}[os.environ.get("PHYS", "ref")]
+flags = {"ref": F_REFERENCE, "c5": F_CONTACT5, "nopads": F_NOPADS, "links": F_REFERENCE_LINKS, "links_c5": F_REFERENCE_LINKS | F_PADS_CUBE,
+         "proxies": F_REFERENCE_PROXIES, "proxies_c5": F_REFERENCE_PROXIES | F_PADS_CUBE}[os.environ.get("PHYS", "ref")]
 env = So100VecEnv(env_id, n, flags=flags, seed=0, stagger_episodes=True)
 sd = RolloutCollector.random_policy_state(env.sim.obs_dim, env.device)
 sd["log_std"] = sd["log_std"] + 0.5                          # a wilder policy than the initial one
