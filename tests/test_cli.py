@@ -50,6 +50,8 @@ def test_cli_errors(tmp_path, monkeypatch):
     if not drv._have_sb3():
         r = CliRunner().invoke(drv.cli, ["-a", "SAC", "train", "-e", "Env01-v1"])
         assert r.exit_code != 0 and "stable-baselines3" in str(r.exception)
+        r = CliRunner().invoke(drv.cli, ["-a", "DDPG", "train", "--help"])        # the reference's DDPG branch (main.py:38-55) has a built-in learner
+        assert r.exit_code == 0 and drv.NATIVE_ALGORITHMS == ("PPO", "DDPG")
     r = CliRunner().invoke(drv.cli, ["-a", "PPO", "train"])                     # -e is required
     assert r.exit_code == 2
     assert drv._default_model_path("Env01-v1", "PPO").startswith(os.path.join("models", "Env01-v1_PPO", "best_model"))
