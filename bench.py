@@ -307,6 +307,13 @@ def main():
     counter = [0]
 
     kev = []                                                 # (start, end, env-steps) HIP event pairs around the dominant kernel's launches
+    evpool = []                                              # event objects are created OUTSIDE the timed regions (only their record() calls are inside)
+
+    def ev_pair():
+        if len(evpool) < 2:                                  # (stepwise modes record a pair per step: refill)
+            evpool.extend(torch.cuda.Event(enable_timing=True) for _ in range(64))
+        return evpool.pop(), evpool.pop()
+    evpool.extend(torch.cuda.Event(enable_timing=True) for _ in range(2*(42*((args.steps + ROLLOUT_T - 1)//ROLLOUT_T) + 4)))
 
     def run(nsteps, record=False):
         """exactly nsteps vectorised env steps, in rollout chunks of at most T steps"""
@@ -319,7 +326,7 @@ def main():
             chunk = chunks[ci][:Tc]
             if args.policy == "persistent":
                 if record:                                   # events on the launch stream (torch's current stream = where the C ABI enqueues)
-                    ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
+                    ea, eb = ev_pair(); ea.record()
                 sim.rollout(chunk, counter[0]); counter[0] += Tc               # ONE launch for Tc steps
                 if record:
                     eb.record(); kev.append((ea, eb, n * Tc))
@@ -329,7 +336,7 @@ def main():
                     if args.policy == "fused":
                         sim.policy_forward(sim.obs, act, counter[0], rollout_row=row)      # obs | action | value | logp -> row
                         if record:
-                            ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
+                            ea, eb = ev_pair(); ea.record()
                         sim.step(act, rollout_row=row)                                     # reward | done -> row
                         if record:
                             eb.record(); kev.append((ea, eb, n))
@@ -341,7 +348,7 @@ def main():
                         row[:, sim.obs_dim:sim.obs_dim + 6] = a
                         a = a.clamp_(-1.0, 1.0)
                         if record:
-                            ea = torch.cuda.Event(enable_timing=True); eb = torch.cuda.Event(enable_timing=True); ea.record()
+                            ea, eb = ev_pair(); ea.record()
                         ob, rew, done, trunc = sim.step(a)
                         if record:
                             eb.record(); kev.append((ea, eb, n))
